@@ -1,0 +1,256 @@
+"""ctypes binding of libfigh.so (include/figh.h).  No torch, no fallback.
+
+``load()`` raises if the shared library is missing; every compute call raises
+``FighError`` when the library reports a failure (no HIP device, bad
+arguments ...).  Nothing in this package computes on the CPU instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfigh.so")
+
+FIGH_OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5
+
+MODE_JOINT_TORQUE, MODE_EXT_WRENCH = 0, 1
+FLAG_FRICTION, FLAG_ACT_INERTIA, FLAG_OFFSET, FLAG_TX40, FLAG_GENERIC = 1, 2, 4, 8, 256
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int32_p = C.POINTER(C.c_int32)
+
+# symbol -> (restype, argtypes); exactly the declarations of include/figh.h
+SIGNATURES = {
+    "figh_version": (C.c_int, []),
+    "figh_last_error": (C.c_char_p, []),
+    "figh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "figh_device_set": (C.c_int, [C.c_int]),
+    "figh_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "figh_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "figh_free": (C.c_int, [C.c_void_p]),
+    "figh_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "figh_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "figh_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "figh_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "figh_synchronize": (C.c_int, []),
+    "figh_profile_enable": (C.c_int, [C.c_int]),
+    "figh_profile_reset": (C.c_int, []),
+    "figh_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), _c_double_p]),
+    "figh_model_create": (C.c_int, [C.c_int, _c_int32_p, _c_int32_p, _c_double_p, _c_double_p, _c_int32_p,
+                                    _c_int32_p, _c_double_p, _c_int32_p, C.POINTER(C.c_void_p)]),
+    "figh_model_destroy": (C.c_int, [C.c_void_p]),
+    "figh_regressor_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "figh_regressor_build": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "figh_coupling_tx40": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "figh_colsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p]),
+    "figh_gather_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "figh_matvec": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "figh_block_sqnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "figh_tsqr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int,
+                            C.c_void_p]),
+    "figh_tsqr_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "figh_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "figh_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "figh_comm_destroy": (C.c_int, []),
+    "figh_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "figh_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_int64]),
+}
+
+
+class FighError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfigh error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libfigh.so (built by ``__graft_entry__.build()`` / ``make -C figaroh_plus_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libfigh.so not found at %s -- build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != FIGH_OK:
+        msg = load().figh_last_error()
+        raise FighError(rc, msg.decode() if msg else "")
+    return rc
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().figh_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    mem = C.c_size_t(0)
+    check(load().figh_device_info(name, 256, C.byref(cus), C.byref(mem)))
+    return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": mem.value}
+
+
+def synchronize():
+    check(load().figh_synchronize())
+
+
+class DeviceArray:
+    """A float64 / int32 buffer in HBM owned by this object (hipMalloc through the C-ABI)."""
+
+    def __init__(self, shape, dtype=np.float64):
+        self.shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if len(self.shape) else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        p = C.c_void_p()
+        check(load().figh_malloc(C.byref(p), max(self.nbytes, 8)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, arr, dtype=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype if dtype is not None else arr.dtype)
+        d = cls(arr.shape, arr.dtype)
+        if arr.nbytes:
+            check(load().figh_memcpy_h2d(d.ptr, arr.ctypes.data, arr.nbytes))
+        return d
+
+    def to_host(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        assert out.nbytes == self.nbytes and out.flags["C_CONTIGUOUS"]
+        if self.nbytes:
+            check(load().figh_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def zero_(self):
+        check(load().figh_memset(self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            load().figh_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def profile_enable(on=True):
+    check(load().figh_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    check(load().figh_profile_reset())
+
+
+def profile_get(name):
+    n = C.c_int(0)
+    ms = C.c_double(0.0)
+    check(load().figh_profile_get(name.encode(), C.byref(n), C.byref(ms)))
+    return n.value, ms.value
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class ModelHandle:
+    """figh_model_t for a flattened tree (``Model.to_flat()``)."""
+
+    def __init__(self, flat):
+        n = int(flat["njoints"])
+        self.njoints, self.nq, self.nv = n, int(flat["nq"]), int(flat["nv"])
+        parents, jtype = _i32(flat["parents"]), _i32(flat["jtype"])
+        idx_q, idx_v = _i32(flat["idx_q"]), _i32(flat["idx_v"])
+        axis, placement, gravity = _f64(flat["axis"]), _f64(flat["placement"]), _f64(flat["gravity"])
+        body_mask = _i32(np.asarray(flat["mass"], dtype=float) != 0.0)
+        h = C.c_void_p()
+        check(load().figh_model_create(
+            n, parents.ctypes.data_as(_c_int32_p), jtype.ctypes.data_as(_c_int32_p),
+            axis.ctypes.data_as(_c_double_p), placement.ctypes.data_as(_c_double_p),
+            idx_q.ctypes.data_as(_c_int32_p), idx_v.ctypes.data_as(_c_int32_p),
+            gravity.ctypes.data_as(_c_double_p), body_mask.ctypes.data_as(_c_int32_p), C.byref(h)))
+        self.handle = h.value
+
+    def shape(self, mode, flags):
+        r, c = C.c_int(0), C.c_int(0)
+        check(load().figh_regressor_shape(self.handle, mode, flags, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            load().figh_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ thin typed wrappers (device pointers)
+def regressor_build(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_W, ldw, d_colsq=None):
+    check(load().figh_regressor_build(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr, d_W.ptr, ldw,
+                                      d_colsq.ptr if d_colsq is not None else None))
+
+
+def coupling_tx40(N, nv, d_v, d_a, d_out):
+    check(load().figh_coupling_tx40(N, nv, d_v.ptr, d_a.ptr, d_out.ptr))
+
+
+def colsq(d_W, rows, cols, ldw, d_out):
+    check(load().figh_colsq(d_W.ptr, rows, cols, ldw, d_out.ptr))
+
+
+def gather_cols(d_W, rows, ldw, d_idx, n, d_out, ldo):
+    check(load().figh_gather_cols(d_W.ptr, rows, ldw, d_idx.ptr, n, d_out.ptr, ldo))
+
+
+def matvec(d_W, rows, ldw, d_idx, n, d_x, d_y):
+    check(load().figh_matvec(d_W.ptr, rows, ldw, d_idx.ptr if d_idx is not None else None, n, d_x.ptr, d_y.ptr))
+
+
+def block_sqnorm(d_a, d_b, rows, nblocks, d_out):
+    check(load().figh_block_sqnorm(d_a.ptr, d_b.ptr if d_b is not None else None, rows, nblocks, d_out.ptr))
+
+
+def tsqr(d_W, rows, ldw, d_idx, n, d_tau, block_weight, d_R):
+    bw = None
+    nb = 0
+    if block_weight is not None:
+        bwa = _f64(block_weight)
+        bw = bwa.ctypes.data_as(_c_double_p)
+        nb = len(bwa)
+    check(load().figh_tsqr(d_W.ptr, rows, ldw, d_idx.ptr if d_idx is not None else None, n,
+                           d_tau.ptr if d_tau is not None else None, bw, nb, d_R.ptr))
+
+
+def tsqr_merge(d_Rs, count, nc, d_R):
+    check(load().figh_tsqr_merge(d_Rs.ptr, count, nc, d_R.ptr))

@@ -1,0 +1,293 @@
+// Runtime plumbing of libfigh.so: device selection, memory, the library stream, per-kernel event timing
+// and the kinematic-tree handle.  No compute lives here.
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "figh_internal.h"
+
+namespace figh {
+
+static thread_local std::string g_error;
+static hipStream_t g_stream = nullptr;
+static bool g_ready = false;
+static bool g_profile = false;
+
+struct ProfileAcc {
+    int launches = 0;
+    double ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static std::map<std::string, ProfileAcc> g_prof;
+
+static void *g_ws[8] = {nullptr};
+static size_t g_ws_bytes[8] = {0};
+
+void set_error(const std::string &msg) { g_error = msg; }
+
+hipStream_t stream() { return g_stream; }
+
+int ensure_device() {
+    if (g_ready) return FIGH_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error(std::string("no HIP device available (") + hipGetErrorString(e) +
+                  "); libfigh has no CPU path");
+        return FIGH_ERR_NO_DEVICE;
+    }
+    FIGH_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_ready = true;
+    return FIGH_OK;
+}
+
+void *workspace(size_t bytes, int slot) {
+    if (bytes <= g_ws_bytes[slot]) return g_ws[slot];
+    if (g_ws[slot]) {
+        (void)hipStreamSynchronize(g_stream);
+        (void)hipFree(g_ws[slot]);
+        g_ws[slot] = nullptr;
+        g_ws_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    if (hipMalloc(&g_ws[slot], want) != hipSuccess) {
+        set_error("workspace allocation failed");
+        return nullptr;
+    }
+    g_ws_bytes[slot] = want;
+    return g_ws[slot];
+}
+
+ProfileScope::ProfileScope(const char *name) : name_(name) {
+    if (!g_profile) return;
+    if (hipEventCreate(&e0_) != hipSuccess || hipEventCreate(&e1_) != hipSuccess) return;
+    (void)hipEventRecord(e0_, g_stream);
+}
+
+ProfileScope::~ProfileScope() {
+    if (!e0_ || !e1_) return;
+    (void)hipEventRecord(e1_, g_stream);
+    g_prof[name_].pending.emplace_back(e0_, e1_);
+}
+
+static void drain_profile() {
+    for (auto &kv : g_prof) {
+        for (auto &p : kv.second.pending) {
+            (void)hipEventSynchronize(p.second);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                kv.second.ms += ms;
+                kv.second.launches += 1;
+            }
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+}  // namespace figh
+
+using namespace figh;
+
+extern "C" {
+
+int figh_version(void) { return 100; }
+
+const char *figh_last_error(void) { return g_error.c_str(); }
+
+int figh_device_count(int *count) {
+    FIGH_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return FIGH_OK;
+}
+
+int figh_device_set(int device) {
+    FIGH_REQUIRE(!g_ready, "figh_device_set must be called before any other device call");
+    FIGH_HIP(hipSetDevice(device));
+    return ensure_device();
+}
+
+int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes) {
+    if (int rc = ensure_device()) return rc;
+    int dev = 0;
+    FIGH_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FIGH_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len > 0) {
+        std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return FIGH_OK;
+}
+
+int figh_malloc(void **d_ptr, size_t bytes) {
+    FIGH_REQUIRE(d_ptr, "d_ptr is NULL");
+    if (int rc = ensure_device()) return rc;
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 8);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+        return FIGH_ERR_ALLOC;
+    }
+    return FIGH_OK;
+}
+
+int figh_free(void *d_ptr) {
+    if (!d_ptr) return FIGH_OK;
+    if (int rc = ensure_device()) return rc;
+    FIGH_HIP(hipStreamSynchronize(g_stream));
+    FIGH_HIP(hipFree(d_ptr));
+    return FIGH_OK;
+}
+
+int figh_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes) {
+    if (int rc = ensure_device()) return rc;
+    FIGH_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g_stream));
+    FIGH_HIP(hipStreamSynchronize(g_stream));
+    return FIGH_OK;
+}
+
+int figh_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes) {
+    if (int rc = ensure_device()) return rc;
+    FIGH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_stream));
+    FIGH_HIP(hipStreamSynchronize(g_stream));
+    return FIGH_OK;
+}
+
+int figh_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes) {
+    if (int rc = ensure_device()) return rc;
+    FIGH_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return FIGH_OK;
+}
+
+int figh_memset(void *d_dst, int value, size_t bytes) {
+    if (int rc = ensure_device()) return rc;
+    FIGH_HIP(hipMemsetAsync(d_dst, value, bytes, g_stream));
+    return FIGH_OK;
+}
+
+int figh_synchronize(void) {
+    if (int rc = ensure_device()) return rc;
+    FIGH_HIP(hipStreamSynchronize(g_stream));
+    return FIGH_OK;
+}
+
+int figh_profile_enable(int on) {
+    g_profile = on != 0;
+    return FIGH_OK;
+}
+
+int figh_profile_reset(void) {
+    if (g_ready) {
+        (void)hipStreamSynchronize(g_stream);
+        drain_profile();
+    }
+    g_prof.clear();
+    return FIGH_OK;
+}
+
+int figh_profile_get(const char *name, int *launches, double *total_ms) {
+    FIGH_REQUIRE(name, "name is NULL");
+    if (g_ready) {
+        FIGH_HIP(hipStreamSynchronize(g_stream));
+        drain_profile();
+    }
+    auto it = g_prof.find(name);
+    if (launches) *launches = it == g_prof.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == g_prof.end() ? 0.0 : it->second.ms;
+    return FIGH_OK;
+}
+
+int figh_model_create(int njoints, const int32_t *parents, const int32_t *jtype, const double *axis,
+                      const double *placement, const int32_t *idx_q, const int32_t *idx_v, const double *gravity,
+                      const int32_t *body_mask, figh_model_t *out) {
+    FIGH_REQUIRE(out, "out is NULL");
+    FIGH_REQUIRE(njoints >= 2 && njoints <= kMaxJoints, "njoints must be in [2, 64]");
+    FIGH_REQUIRE(parents && jtype && axis && placement && idx_q && idx_v && gravity && body_mask, "NULL array");
+    if (int rc = ensure_device()) return rc;
+    auto *m = new figh_model_s();
+    DevModel &h = m->host;
+    std::memset(&h, 0, sizeof(h));
+    h.njoints = njoints;
+    h.nlinks = njoints - 1;
+    bool chain = true;
+    int nq = 0, nv = 0;
+    for (int i = 0; i < njoints; ++i) {
+        h.parents[i] = parents[i];
+        h.jtype[i] = jtype[i];
+        h.idx_q[i] = idx_q[i];
+        h.idx_v[i] = idx_v[i];
+        h.body_mask[i] = body_mask[i] != 0;
+        for (int k = 0; k < 3; ++k) h.axis[i][k] = axis[3 * i + k];
+        for (int k = 0; k < 12; ++k) h.placement[i][k] = placement[12 * i + k];
+        if (i == 0) continue;
+        if (parents[i] < 0 || parents[i] >= i) {
+            delete m;
+            set_error("parents[i] must satisfy 0 <= parents[i] < i (depth-first numbering)");
+            return FIGH_ERR_INVALID;
+        }
+        h.depth[i] = h.depth[parents[i]] + 1;
+        if (h.depth[i] > m->max_depth) m->max_depth = h.depth[i];
+        int jq, jv;
+        switch (jtype[i]) {
+            case FIGH_JT_REVOLUTE: jq = 1; jv = 1; break;
+            case FIGH_JT_PRISMATIC: jq = 1; jv = 1; break;
+            case FIGH_JT_CONTINUOUS: jq = 2; jv = 1; break;
+            case FIGH_JT_FREEFLYER: jq = 7; jv = 6; break;
+            default:
+                delete m;
+                set_error("unsupported joint type");
+                return FIGH_ERR_INVALID;
+        }
+        if (idx_q[i] != nq || idx_v[i] != nv) {
+            delete m;
+            set_error("idx_q / idx_v must be cumulative in joint order");
+            return FIGH_ERR_INVALID;
+        }
+        nq += jq;
+        nv += jv;
+        if (jtype[i] != FIGH_JT_REVOLUTE || parents[i] != i - 1) chain = false;
+    }
+    for (int k = 0; k < 3; ++k) h.gravity[k] = gravity[k];
+    h.nq = nq;
+    h.nv = nv;
+    m->is_chain = chain && h.nlinks <= 8;
+    if (hipMalloc(&m->dev, sizeof(DevModel)) != hipSuccess) {
+        delete m;
+        set_error("hipMalloc(model) failed");
+        return FIGH_ERR_ALLOC;
+    }
+    FIGH_HIP(hipMemcpy(m->dev, &h, sizeof(DevModel), hipMemcpyHostToDevice));
+    *out = m;
+    return FIGH_OK;
+}
+
+int figh_model_destroy(figh_model_t model) {
+    if (!model) return FIGH_OK;
+    if (g_ready) (void)hipStreamSynchronize(g_stream);
+    if (model->dev) (void)hipFree(model->dev);
+    delete model;
+    return FIGH_OK;
+}
+
+int figh_regressor_shape(figh_model_t model, int mode, int flags, int *rows_per_sample, int *ncols) {
+    FIGH_REQUIRE(model, "model is NULL");
+    FIGH_REQUIRE(mode == FIGH_MODE_JOINT_TORQUE || mode == FIGH_MODE_EXT_WRENCH, "bad mode");
+    const DevModel &h = model->host;
+    if (mode == FIGH_MODE_JOINT_TORQUE) {
+        // the reference's joint-torque branch sizes W as (N*nv, 14*nv) and copies a (nv x 10*(njoints-1))
+        // block into its first 10*nv columns (regressor.py:46,52): only consistent when njoints-1 == nv
+        FIGH_REQUIRE(h.nlinks == h.nv, "joint-torque mode needs njoints-1 == nv (one dof per joint)");
+    }
+    if (flags & FIGH_FLAG_TX40) {
+        FIGH_REQUIRE(mode == FIGH_MODE_JOINT_TORQUE && h.nv == 6, "TX40 coupling needs a 6-dof joint-torque model");
+    }
+    if (rows_per_sample) *rows_per_sample = mode == FIGH_MODE_JOINT_TORQUE ? h.nv : 6;
+    if (ncols) *ncols = 14 * h.nlinks + ((flags & FIGH_FLAG_TX40) ? 3 : 0);
+    return FIGH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Internal declarations shared by the translation units of libfigh.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "figh.h"
+
+namespace figh {
+
+constexpr int kMaxJoints = 64;  // flattened trees up to 63 joints + universe (human model: 41)
+
+// Device-resident copy of the kinematic tree; every index into it is wave-uniform, so the compiler
+// fetches it through the scalar cache into SGPRs.
+struct DevModel {
+    int njoints, nq, nv, nlinks;
+    int parents[kMaxJoints];
+    int jtype[kMaxJoints];
+    int idx_q[kMaxJoints];
+    int idx_v[kMaxJoints];
+    int body_mask[kMaxJoints];
+    int depth[kMaxJoints];
+    double axis[kMaxJoints][3];
+    double placement[kMaxJoints][12];
+    double gravity[3];
+};
+
+}  // namespace figh
+
+struct figh_model_s {
+    figh::DevModel host;
+    figh::DevModel *dev = nullptr;
+    bool is_chain = false;  // fixed-base serial chain of revolute joints: eligible for the chain kernel
+    int max_depth = 0;
+};
+
+namespace figh {
+
+void set_error(const std::string &msg);
+hipStream_t stream();
+int ensure_device();
+
+// per-kernel-family hipEvent timing (figh_profile_*)
+struct ProfileScope {
+    explicit ProfileScope(const char *name);
+    ~ProfileScope();
+    const char *name_;
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;
+};
+
+// scratch buffer owned by the library, grown on demand (device)
+void *workspace(size_t bytes, int slot);
+
+#define FIGH_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            figh::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return FIGH_ERR_NO_DEVICE;                                                          \
+        }                                                                                       \
+    } while (0)
+
+#define FIGH_REQUIRE(cond, msg)              \
+    do {                                     \
+        if (!(cond)) {                       \
+            figh::set_error(msg);            \
+            return FIGH_ERR_INVALID;         \
+        }                                    \
+    } while (0)
+
+}  // namespace figh

@@ -1,0 +1,442 @@
+// K2 / K3 -- column norms, gathers, residual norms and the tall-skinny Householder QR on gfx950.
+//
+// figh_tsqr replaces the np.linalg.qr calls of src/figaroh/tools/qrdecomposition.py:105,205,238,286.  The
+// reference only consumes R (|diag R| > tol rank test, R1 / R2 regrouping) and Q1^T tau, never Q itself
+// (W_b = Q1 R1 is re-derived as the gathered base columns, qrdecomposition.py:268-269), so the kernel streams
+// the rows of W once and keeps only the n x n triangle.
+//
+// Kernel mapping (tsqr_kernel<CPL, M>): one wavefront owns a contiguous range of rows and a private R.
+// Lane l owns columns l, l+64, ... (CPL per lane): a tile of M rows sits in registers, B[c][r].  For each
+// column k the pivot column is broadcast across the wave (ds_bpermute, no LDS traffic), every lane forms
+// x^T B[:, col] for its own columns in M FMAs, and the Householder update of the stacked [R; tile]
+// ("triangle on top of a rectangle", LAPACK tpqrt structure) costs another M FMAs per column -- 2*m*n^2
+// flops for m appended rows, no wasted work on the triangle.  Tiles whose leading columns are structurally
+// zero (rows of joint j have zeros for links < j in the joint-torque layout) start at their first non-zero
+// column.  The per-wave triangles are then reduced by the same kernel over the stacked R factors (fan-in 4
+// per level).  Householder throughout: the rank decision |R_kk| > 1e-8 needs ~eps*||col|| accuracy on
+// dependent pivots, which a Gram/Cholesky route cannot give.
+//
+// fp64 on gfx950: v_mfma_f64_16x16x4 and the fp64 VALU FMA have the SAME peak (78.6 TFLOP/s), so for n ~ 50
+// (a 16-wide Householder panel would leave the matrix pipe waiting on the panel's reductions) the wave-level
+// VALU formulation is used; the roofline this kernel is priced against is that fp64 peak.
+#include "figh_internal.h"
+
+namespace figh {
+
+__device__ __forceinline__ double bcast_v(double x, int src_lane) {  // value of lane src_lane, in a VGPR
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_s(double x, int src_lane) {  // wave-uniform (SGPR) copy
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CPL, int M, bool RLDS>
+__global__ __launch_bounds__(64) void tsqr_kernel(const double *__restrict__ W, const long rows, const long ldw,
+                                                  const int *__restrict__ col_idx, const int n,
+                                                  const double *__restrict__ tau, const double *__restrict__ blkw,
+                                                  const long rows_per_blk, const long rows_per_wave,
+                                                  double *__restrict__ Rws, const int nc) {
+    const int lane = threadIdx.x;
+    const long wave = blockIdx.x;
+    const long rbeg = wave * rows_per_wave;
+    const long rend = (rbeg + rows_per_wave < rows) ? rbeg + rows_per_wave : rows;
+
+    __shared__ double Rl[RLDS ? 64 * 64 : 1];
+    double *Rg = Rws + wave * (long)nc * nc;  // private triangle; also the working copy when !RLDS
+
+    int kind[CPL];
+    long coff[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int col = lane + 64 * c;
+        if (col < n) {
+            kind[c] = 1;
+            coff[c] = col_idx ? col_idx[col] : col;
+        } else if (col == n && tau != nullptr) {
+            kind[c] = 2;
+            coff[c] = 0;
+        } else {
+            kind[c] = 0;
+            coff[c] = 0;
+        }
+    }
+    if constexpr (RLDS) {
+        for (int k = 0; k < 64; ++k) Rl[k * 64 + lane] = 0.0;
+    } else {
+        for (int k = 0; k < nc; ++k)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (lane + 64 * c < nc) Rg[(long)k * nc + lane + 64 * c] = 0.0;
+    }
+    __syncthreads();
+
+    for (long r0 = rbeg; r0 < rend; r0 += M) {
+        double B[CPL][M];
+        long blk = blkw ? r0 / rows_per_blk : 0;
+        long next_blk = (blk + 1) * rows_per_blk;
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const long row = r0 + r;
+            const bool inb = row < rend;
+            double scale = 1.0;
+            if (blkw && inb) {
+                if (row >= next_blk) {
+                    ++blk;
+                    next_blk += rows_per_blk;
+                }
+                scale = blkw[blk];
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                double x = 0.0;
+                if (inb) {
+                    if (kind[c] == 1) x = W[row * ldw + coff[c]] * scale;
+                    else if (kind[c] == 2) x = tau[row] * scale;
+                }
+                B[c][r] = x;
+            }
+        }
+        int kstart = nc;
+#pragma unroll
+        for (int c = CPL - 1; c >= 0; --c) {
+            bool nz = false;
+#pragma unroll
+            for (int r = 0; r < M; ++r) nz |= (B[c][r] != 0.0);
+            const unsigned long long mask = __ballot(nz);
+            if (mask) kstart = 64 * c + (__ffsll((long long)mask) - 1);
+        }
+
+        for (int k = kstart; k < nc; ++k) {
+            const int kc = k >> 6, kl = k & 63;
+            double xs[M];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                if (c == kc) {
+#pragma unroll
+                    for (int r = 0; r < M; ++r) xs[r] = bcast_v(B[c][r], kl);
+                }
+            }
+            double d[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int r = 0; r < M; r += 4) {
+                    s0 += xs[r] * B[c][r];
+                    s1 += xs[r + 1] * B[c][r + 1];
+                    s2 += xs[r + 2] * B[c][r + 2];
+                    s3 += xs[r + 3] * B[c][r + 3];
+                }
+                d[c] = (s0 + s1) + (s2 + s3);
+            }
+            double dk = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (c == kc) dk = d[c];
+            const double sigma = bcast_s(dk, kl);
+            if (sigma == 0.0) continue;  // column already zero below the triangle: H = I (LAPACK dlarfg)
+
+            double Rk[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int col = lane + 64 * c;
+                if constexpr (RLDS) {
+                    Rk[c] = Rl[k * 64 + lane];
+                } else {
+                    Rk[c] = col < nc ? Rg[(long)k * nc + col] : 0.0;
+                }
+            }
+            double rkk = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (c == kc) rkk = Rk[c];
+            const double alpha = bcast_s(rkk, kl);
+            const double beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+            const double inv = 1.0 / (alpha - beta);
+            const double tfac = (beta - alpha) / beta;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int col = lane + 64 * c;
+                const bool trail = col > k && col < nc;
+                const double wj = trail ? (Rk[c] + d[c] * inv) * tfac : 0.0;
+                const double cj = wj * inv;
+                Rk[c] = (col == k) ? beta : Rk[c] - wj;
+#pragma unroll
+                for (int r = 0; r < M; ++r) B[c][r] -= cj * xs[r];
+                if constexpr (RLDS) {
+                    Rl[k * 64 + lane] = Rk[c];
+                } else {
+                    if (col < nc) Rg[(long)k * nc + col] = Rk[c];
+                }
+            }
+        }
+    }
+    if constexpr (RLDS) {
+        __syncthreads();
+        for (int k = 0; k < nc; ++k)
+            if (lane < nc) Rg[(long)k * nc + lane] = Rl[k * 64 + lane];
+    }
+}
+
+// diag(W^T W): block b owns a slab of rows; thread t owns columns t, t+256, ...; partial[b][c] then a
+// fixed-order reduction (deterministic).
+__global__ __launch_bounds__(256) void colsq_kernel(const double *__restrict__ W, long rows, int cols, long ldw,
+                                                    long rows_per_block, double *__restrict__ part) {
+    const long rb = (long)blockIdx.x * rows_per_block;
+    const long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        double s0 = 0.0, s1 = 0.0;
+        long r = rb;
+        for (; r + 1 < re; r += 2) {
+            const double x0 = W[r * ldw + c], x1 = W[(r + 1) * ldw + c];
+            s0 += x0 * x0;
+            s1 += x1 * x1;
+        }
+        if (r < re) {
+            const double x0 = W[r * ldw + c];
+            s0 += x0 * x0;
+        }
+        part[(long)blockIdx.x * cols + c] = s0 + s1;
+    }
+}
+
+__global__ void reduce_cols_kernel(const double *__restrict__ part, int nblocks, int ncols, double *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long)b * ncols + c];
+    out[c] = s;
+}
+
+__global__ __launch_bounds__(256) void gather_cols_kernel(const double *__restrict__ W, long rows, long ldw,
+                                                          const int *__restrict__ col_idx, int n,
+                                                          double *__restrict__ out, long ldo) {
+    const long total = rows * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / n;
+        const int c = (int)(e - r * n);
+        out[r * ldo + c] = W[r * ldw + col_idx[c]];
+    }
+}
+
+// y[r] = sum_c W[r, idx[c]] x[c]; one wave per row-group, lanes across columns, wave reduction
+__global__ __launch_bounds__(256) void matvec_kernel(const double *__restrict__ W, long rows, long ldw,
+                                                     const int *__restrict__ col_idx, int n,
+                                                     const double *__restrict__ x, double *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = wave; r < rows; r += nwaves) {
+        double s = 0.0;
+        for (int c = lane; c < n; c += 64) s += W[r * ldw + (col_idx ? col_idx[c] : c)] * x[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) y[r] = s;
+    }
+}
+
+// out[b] = sum over block b of (a - b)^2, one workgroup per block, fixed reduction order
+__global__ __launch_bounds__(256) void block_sqnorm_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                           long rows_per_block, double *__restrict__ out) {
+    __shared__ double sm[256];
+    const long base = (long)blockIdx.x * rows_per_block;
+    double s = 0.0;
+    for (long r = threadIdx.x; r < rows_per_block; r += 256) {
+        const double d = a[base + r] - (b ? b[base + r] : 0.0);
+        s += d * d;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+static int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// one TSQR level: rows of (W, ldw) -> nw triangles in Rws.  Returns nw (>0) or a negative status.
+static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
+                       const double *d_blkw, long rows_per_blk, int nc, long target_waves, long align,
+                       double *Rws_out, long *nw_out) {
+    int M;
+    if (nc <= 64) M = 64;
+    else if (nc <= 128) M = 32;
+    else M = 16;
+    if (align < M) align = M;
+    long rpw = (rows + target_waves - 1) / target_waves;
+    rpw = ((rpw + align - 1) / align) * align;
+    const long nw = (rows + rpw - 1) / rpw;
+    *nw_out = nw;
+    dim3 grid((unsigned)nw), block(64);
+#define FIGH_TSQR_LAUNCH(CPL, MM, RL)                                                                          \
+    hipLaunchKernelGGL((tsqr_kernel<CPL, MM, RL>), grid, block, 0, stream(), W, rows, ldw, col_idx, n, tau,     \
+                       d_blkw, rows_per_blk, rpw, Rws_out, nc)
+    if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
+    else if (nc <= 128) FIGH_TSQR_LAUNCH(2, 32, false);
+    else if (nc <= 256) FIGH_TSQR_LAUNCH(4, 16, false);
+    else if (nc <= 384) FIGH_TSQR_LAUNCH(6, 16, false);
+    else {
+        set_error("figh_tsqr: more than 384 columns not supported yet");
+        return FIGH_ERR_UNSUPPORTED;
+    }
+#undef FIGH_TSQR_LAUNCH
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+// reduce `count` stacked nc x nc triangles (in Rs, contiguous) down to one, result in d_R_out
+static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out) {
+    const size_t tri = sizeof(double) * (size_t)nc * nc;
+    const double *cur = Rs;
+    long cnt = count;
+    int slot = 2;
+    while (cnt > 1) {
+        const long fan = 4;
+        const long nw_next = (cnt + fan - 1) / fan;
+        double *dst = nw_next == 1 ? d_R_out : static_cast<double *>(workspace(tri * nw_next, slot));
+        if (!dst) return FIGH_ERR_ALLOC;
+        long nw = 0;
+        ProfileScope scope("tsqr_reduce");
+        if (int rc = tsqr_level(cur, cnt * nc, nc, nullptr, nc, nullptr, nullptr, 1, nc, nw_next, fan * nc, dst, &nw))
+            return rc;
+        cur = dst;
+        cnt = nw;
+        slot = slot == 2 ? 3 : 2;
+    }
+    if (cur != d_R_out) FIGH_HIP(hipMemcpyAsync(d_R_out, cur, tri, hipMemcpyDeviceToDevice, stream()));
+    return FIGH_OK;
+}
+
+}  // namespace figh
+
+using namespace figh;
+
+extern "C" {
+
+int figh_colsq(const double *d_W, int64_t rows, int cols, int64_t ldw, double *d_out) {
+    FIGH_REQUIRE(d_W && d_out, "NULL device pointer");
+    FIGH_REQUIRE(rows >= 0 && cols > 0 && ldw >= cols, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    if (rows == 0) {
+        FIGH_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * cols, stream()));
+        return FIGH_OK;
+    }
+    long nblocks = cu_count() * 8L;
+    long rpb = (rows + nblocks - 1) / nblocks;
+    if (rpb < 16) rpb = 16;
+    nblocks = (rows + rpb - 1) / rpb;
+    double *part = static_cast<double *>(workspace(sizeof(double) * nblocks * cols, 1));
+    if (!part) return FIGH_ERR_ALLOC;
+    ProfileScope scope("colsq");
+    hipLaunchKernelGGL(colsq_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream(), d_W, (long)rows, cols, (long)ldw,
+                       rpb, part);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((cols + 127) / 128), dim3(128), 0, stream(), part, (int)nblocks, cols,
+                       d_out);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int figh_gather_cols(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, double *d_out,
+                     int64_t ldo) {
+    FIGH_REQUIRE(d_W && d_out && d_col_idx, "NULL device pointer");
+    FIGH_REQUIRE(rows >= 0 && n >= 0 && ldo >= n, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    if (rows == 0 || n == 0) return FIGH_OK;
+    long blocks = (rows * n + 255) / 256;
+    if (blocks > cu_count() * 16L) blocks = cu_count() * 16L;
+    ProfileScope scope("gather_cols");
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_W, (long)rows, (long)ldw,
+                       d_col_idx, n, d_out, (long)ldo);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int figh_matvec(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_x,
+                double *d_y) {
+    FIGH_REQUIRE(d_W && d_x && d_y, "NULL device pointer");
+    FIGH_REQUIRE(rows >= 0 && n > 0, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    if (rows == 0) return FIGH_OK;
+    long blocks = (rows + 3) / 4;
+    if (blocks > cu_count() * 8L) blocks = cu_count() * 8L;
+    ProfileScope scope("matvec");
+    hipLaunchKernelGGL(matvec_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_W, (long)rows, (long)ldw,
+                       d_col_idx, n, d_x, d_y);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int figh_block_sqnorm(const double *d_a, const double *d_b, int64_t rows, int nblocks, double *d_out) {
+    FIGH_REQUIRE(d_a && d_out, "NULL device pointer");
+    FIGH_REQUIRE(nblocks > 0 && rows >= 0 && rows % nblocks == 0, "rows must be a multiple of nblocks");
+    if (int rc = ensure_device()) return rc;
+    ProfileScope scope("block_sqnorm");
+    hipLaunchKernelGGL(block_sqnorm_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream(), d_a, d_b,
+                       (long)(rows / nblocks), d_out);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
+              const double *h_block_weight, int nblocks, double *d_R_out) {
+    FIGH_REQUIRE(d_W && d_R_out, "NULL device pointer");
+    FIGH_REQUIRE(rows > 0 && n > 0 && ldw > 0, "bad shape");
+    const int nc = n + (d_tau ? 1 : 0);
+    FIGH_REQUIRE(nc <= 384, "figh_tsqr: more than 384 columns not supported yet");
+    if (int rc = ensure_device()) return rc;
+    const double *d_blkw = nullptr;
+    long rows_per_blk = 1;
+    if (h_block_weight) {
+        FIGH_REQUIRE(nblocks > 0 && rows % nblocks == 0, "rows must be a multiple of nblocks");
+        double *wbuf = static_cast<double *>(workspace(sizeof(double) * nblocks, 4));
+        if (!wbuf) return FIGH_ERR_ALLOC;
+        FIGH_HIP(hipMemcpyAsync(wbuf, h_block_weight, sizeof(double) * nblocks, hipMemcpyHostToDevice, stream()));
+        FIGH_HIP(hipStreamSynchronize(stream()));
+        d_blkw = wbuf;
+        rows_per_blk = rows / nblocks;
+    }
+    // level 0: one wave per SIMD for the register-resident n <= 64 kernel, fewer for the wide ones
+    long target = nc <= 64 ? cu_count() * 4L : cu_count() * 2L;
+    const size_t tri = sizeof(double) * (size_t)nc * nc;
+    long nw_est = target + 1;
+    double *Rws = static_cast<double *>(workspace(tri * nw_est, 5));
+    if (!Rws) return FIGH_ERR_ALLOC;
+    long nw = 0;
+    {
+        ProfileScope scope("tsqr");
+        if (int rc = tsqr_level(d_W, rows, ldw, d_col_idx, n, d_tau, d_blkw, rows_per_blk, nc, target, 64, Rws, &nw))
+            return rc;
+    }
+    if (nw == 1) {
+        FIGH_HIP(hipMemcpyAsync(d_R_out, Rws, tri, hipMemcpyDeviceToDevice, stream()));
+        return FIGH_OK;
+    }
+    return tsqr_reduce(Rws, nw, nc, d_R_out);
+}
+
+int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out) {
+    FIGH_REQUIRE(d_Rs && d_R_out, "NULL device pointer");
+    FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 384, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    if (count == 1) {
+        FIGH_HIP(hipMemcpyAsync(d_R_out, d_Rs, sizeof(double) * (size_t)nc * nc, hipMemcpyDeviceToDevice, stream()));
+        return FIGH_OK;
+    }
+    return tsqr_reduce(d_Rs, count, nc, d_R_out);
+}
+
+}  // extern "C"

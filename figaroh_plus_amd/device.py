@@ -1,0 +1,72 @@
+"""Device-resident matrices for the drop-in functions.
+
+The reference's functions take and return NumPy arrays.  The
+mirrors in ``tools/`` accept either a NumPy array (uploaded for the call) or a
+:class:`GpuMatrix`, and return NumPy arrays unless the caller passed
+``param["device_resident"] = True`` / a ``GpuMatrix``, so a script can keep the
+stacked regressor in HBM between ``build_regressor_basic`` ->
+``get_index_eliminate`` -> ``build_regressor_reduced`` -> ``get_baseParams``
+instead of paying a PCIe round trip per call.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class GpuMatrix:
+    """rows x cols float64, row-major with leading dimension ``ld``, in HBM."""
+
+    def __init__(self, buf, rows, cols, ld=None):
+        self.buf = buf
+        self.rows, self.cols = int(rows), int(cols)
+        self.ld = int(ld if ld is not None else cols)
+
+    @property
+    def shape(self):
+        return (self.rows, self.cols)
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    @classmethod
+    def empty(cls, rows, cols):
+        return cls(_lib.DeviceArray((max(int(rows) * int(cols), 1),), np.float64), rows, cols)
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if arr.ndim != 2:
+            raise ValueError("expected a 2-D array, got shape %r" % (arr.shape,))
+        return cls(_lib.DeviceArray.from_host(arr.reshape(-1)), arr.shape[0], arr.shape[1])
+
+    def numpy(self):
+        assert self.ld == self.cols
+        out = np.empty((self.rows, self.cols))
+        if out.size:
+            _lib.check(_lib.load().figh_memcpy_d2h(out.ctypes.data, self.buf.ptr, out.nbytes))
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self.rows
+
+
+def to_device(W):
+    """(GpuMatrix, was_already_on_device)"""
+    if isinstance(W, GpuMatrix):
+        return W, True
+    return GpuMatrix.from_host(W), False
+
+
+def vector_to_device(x):
+    if isinstance(x, _lib.DeviceArray):
+        return x
+    return _lib.DeviceArray.from_host(np.ascontiguousarray(x, dtype=np.float64).reshape(-1))
+
+
+def index_to_device(idx):
+    return _lib.DeviceArray.from_host(np.ascontiguousarray(idx, dtype=np.int32))

@@ -1,0 +1,150 @@
+"""HIP-backed mirror of the LS / WLS / sigma helpers of
+``src/figaroh/identification/identification_tools.py`` (:23-83, :168-331) plus the
+least-squares statements that live inline in the example scripts.
+
+Every pass over the tall matrices (residuals, weighted normal equations, covariance) is a
+TSQR / block-norm kernel call; what remains on the host is O(r^2) algebra on the triangle.
+"""
+import operator
+
+import numpy as np
+
+from .. import _lib
+from ..device import to_device, vector_to_device
+from ..tools.qrdecomposition import rfactor
+
+
+def get_param_from_yaml(robot, identif_data):
+    """Flatten the YAML ``identification`` section into the ``param`` dict (identification_tools.py:23-83)."""
+    rp = identif_data["robot_params"][0]
+    pb = identif_data["problem_params"][0]
+    pr = identif_data["processing_params"][0]
+    tls = identif_data["tls_params"][0]
+    param = {"robot_name": robot.model.name, "nb_samples": int(1 / (pr["ts"]))}
+    for key in ("q_lim_def", "dq_lim_def", "fv", "fs", "Ia", "Iam6", "fvm6", "fsm6", "N", "ratio_essential"):
+        param[key] = rp[key]
+    param["off"] = rp["offset"]
+    for key in ("is_external_wrench", "is_joint_torques", "force_torque", "external_wrench_offsets", "has_friction",
+                "has_actuator_inertia", "has_joint_offset", "has_coupled_wrist"):
+        param[key] = pb[key]
+    param["cut_off_frequency_butterworth"] = pr["cut_off_frequency_butterworth"]
+    param["ts"] = pr["ts"]
+    param["mass_load"] = tls["mass_load"]
+    param["which_body_loaded"] = tls["which_body_loaded"]
+    return param
+
+
+def base_param_from_standard(phi_standard, params_base):
+    """Evaluate the regrouping expressions on standard-parameter values (identification_tools.py:168-201)."""
+    ops = {"+": operator.add, "-": operator.sub}
+    phi_base = []
+    for expr in params_base:
+        values, pending = [], []
+        for tok in expr.split(" "):
+            parts = tok.split("*")
+            if len(parts) == 2:
+                values.append(float(parts[0]) * phi_standard[parts[1]])
+            elif parts[0] in ops:
+                pending.append(ops[parts[0]])
+            else:
+                values.append(phi_standard[parts[0]])
+        acc = values[0]
+        for k, op in enumerate(pending):
+            acc = op(acc, values[k + 1])
+        phi_base.append(acc)
+    return phi_base
+
+
+def index_in_base_params(params, id_segments):
+    """Map segment ids to the base parameters that contain them (identification_tools.py:237-288)."""
+    names = ("Ixx", "Ixy", "Ixz", "Iyy", "Iyz", "Izz", "mx", "my", "mz", "m")
+    hits = set()
+    for seg in id_segments:
+        wanted = {k + str(seg) for k in names}
+        for ii, expr in enumerate(params):
+            for tok in expr.split(" "):
+                if any(p in wanted for p in tok.split("*")):
+                    hits.add((seg, ii))
+    grouped = {}
+    for seg, ii in sorted(hits):
+        grouped.setdefault(seg, []).append(ii)
+    return dict(zip(range(len(id_segments)), grouped.values()))
+
+
+def _triangle_with_tau(W_b, tau, block_weight=None):
+    Raug = rfactor(W_b, tau=tau, block_weight=block_weight)
+    r = Raug.shape[0] - 1
+    return Raug[:r, :r], Raug[:r, r], Raug[r, r]
+
+
+def least_squares(W_b, tau):
+    """OLS solution of ``W_b phi = tau`` -- replaces ``np.linalg.pinv(W_base) @ tau``
+    (examples/ur10/identification.py:159, examples/human/identification.py:467) and
+    ``np.linalg.lstsq(W_b, tau)`` (examples/staubli_TX40/identification.py:240) for full-rank W_b."""
+    R, z, _ = _triangle_with_tau(W_b, tau)
+    return np.linalg.solve(R, z)
+
+
+def relative_stdev(W_b, phi_b, tau):
+    """Relative standard deviation (%) of the identified parameters (identification_tools.py:204-234).
+
+    ||tau - W phi||^2 = ||R phi - Q^T tau||^2 + rho^2 and inv(W^T W) = R^-1 R^-T, both from one TSQR.
+    """
+    Wd, _ = to_device(W_b)
+    phi_b = np.asarray(phi_b, dtype=np.float64)
+    R, z, rho = _triangle_with_tau(Wd, tau)
+    res2 = float(np.sum((R @ phi_b - z) ** 2) + rho ** 2)
+    sig_ro_sqr = res2 / (Wd.rows - phi_b.shape[0])
+    R_inv = np.linalg.inv(R)
+    C_x = sig_ro_sqr * (R_inv @ R_inv.T)
+    std_x_sqr = np.diag(C_x)
+    std_xr = np.zeros(std_x_sqr.shape[0])
+    for i in range(std_x_sqr.shape[0]):
+        std_xr[i] = np.round(100 * np.sqrt(std_x_sqr[i]) / np.abs(phi_b[i]), 2)
+    return std_xr
+
+
+def block_residual_sqnorms(tau_meas, tau_est, nblocks):
+    """Per-joint squared residual norms ||tau_j - tau_est_j||^2 on the device."""
+    d_a, d_b = vector_to_device(tau_meas), vector_to_device(tau_est)
+    out = _lib.DeviceArray((nblocks,), np.float64)
+    _lib.block_sqnorm(d_a, d_b, d_a.size, nblocks, out)
+    return out.to_host()
+
+
+def weigthed_least_squares(robot, phi_b, W_b, tau_meas, tau_est, param):
+    """Library WLS (identification_tools.py:291-331), including its conventions: per-joint
+    ``sigma_j = ||tau_j - tau_est_j|| / (n_j - len(phi_b))`` (a norm, not a variance), rows scaled by
+    ``1/sigma_j``, ``phi = pinv(P W) P tau`` with all joints weighted, rounded to 6 decimals."""
+    nq = robot.model.nq
+    stops = [int(s) for s in param["idx_tau_stop"]][:nq]
+    nb = stops[0]
+    if stops != [nb * (k + 1) for k in range(nq)]:
+        raise ValueError("weigthed_least_squares: idx_tau_stop must describe equal-length joint blocks "
+                         "(the reference's P index jj + ii*nb_samples assumes it, identification_tools.py:319-321)")
+    Wd, _ = to_device(W_b)
+    tau_meas = np.ascontiguousarray(tau_meas, dtype=np.float64)
+    if Wd.rows != nb * nq or tau_meas.shape[0] != Wd.rows:
+        raise ValueError("W_b / tau_meas do not match idx_tau_stop")
+    sq = block_residual_sqnorms(tau_meas, tau_est, nq)
+    sigma = np.sqrt(sq) / (nb - len(phi_b))
+    R, z, _ = _triangle_with_tau(Wd, tau_meas, block_weight=1.0 / sigma)
+    return np.around(np.linalg.solve(R, z), 6)
+
+
+def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks):
+    """Script WLS of examples/staubli_TX40/identification.py:305-346 for ``nblocks`` equal joint blocks:
+    sigma_j^2 = ||tau_j - W_j phi_b||^2 / n_j, phi = (W^T S^-1 W)^-1 W^T S^-1 tau (6 decimals),
+    C_X = (W^T S^-1 W)^-1, std% = 100 sqrt(diag C_X) / |phi| (2 decimals).  Returns (phi, std%)."""
+    Wd, _ = to_device(W_b)
+    phi_b = np.ascontiguousarray(phi_b, dtype=np.float64)
+    d_est = _lib.DeviceArray((Wd.rows,), np.float64)
+    _lib.matvec(Wd.buf, Wd.rows, Wd.ld, None, Wd.cols, vector_to_device(phi_b), d_est)
+    sq = block_residual_sqnorms(tau, d_est, nblocks)
+    sig2 = sq / (Wd.rows // nblocks)
+    R, z, _ = _triangle_with_tau(Wd, tau, block_weight=1.0 / np.sqrt(sig2))
+    phi = np.around(np.linalg.solve(R, z), 6)
+    R_inv = np.linalg.inv(R)
+    C_X = R_inv @ R_inv.T
+    std = np.round(100 * np.sqrt(np.diag(C_X)) / np.abs(phi), 2)
+    return phi, std

@@ -1,0 +1,122 @@
+"""Device-resident identification pass: (q, v, a[, tau]) in HBM -> idx_e, idx_base, beta, phi on the host.
+
+This is the sequence every ``examples/*/identification.py`` of the reference runs
+(SURVEY.md section 3.1-3.3)::
+
+    W  = build_regressor_basic(...)            [+ add_coupling_TX40]      K1 (+ fused diag(W^T W))
+    idx_e, params_r = get_index_eliminate(W, params_std, tol_e)           84..560 doubles to the host
+    W_e = build_regressor_reduced(W, idx_e)                               never materialised: column gather
+    _, params_base, idx_base = get_baseParams(W_e, params_r, params_std)  K3 TSQR over W[:, kept] (+ tau)
+    phi_b = pinv(W_b) @ tau  /  double_QR                                 from the same triangle
+
+kept in HBM between the steps, so one "step" of bench.py is exactly this function.  Multi-GPU:
+each rank runs it on its own shard of samples; column norms are summed and the per-rank triangles
+stacked (``exchange``), then reduced once more.
+"""
+import numpy as np
+
+from . import _lib
+from .device import GpuMatrix
+from .tools import qrdecomposition as qrd
+from .tools.regressor import build_regressor_device
+
+
+class Exchange:
+    """Single-process default: nothing to exchange."""
+
+    world_size = 1
+    rank = 0
+
+    def sum_columns(self, d_colsq, ncols):
+        return d_colsq.to_host()
+
+    def stack_triangles(self, d_R, nc):
+        return d_R, 1
+
+
+class IdentificationPipeline:
+    def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None):
+        self.robot, self.param, self.coupling = robot, param, coupling
+        self.tol_e, self.tol_qr = tol_e, tol_qr
+        self.params_std = params_std if params_std is not None else robot.get_standard_parameters(param)
+        self.names = list(self.params_std.keys())
+        self.exchange = exchange or Exchange()
+        self.N = 0
+        self.d_q = self.d_v = self.d_a = self.d_tau = None
+        self.W = None
+
+    # ------------------------------------------------------------------ inputs
+    def set_samples(self, q, v, a, tau=None):
+        """Upload this rank's samples (q: N x nq, v/a: N x nv) and optionally tau (rows of W,)."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        self.N = len(q)
+        self.d_q = _lib.DeviceArray.from_host(q.reshape(-1))
+        self.d_v = _lib.DeviceArray.from_host(np.ascontiguousarray(v, dtype=np.float64).reshape(-1))
+        self.d_a = _lib.DeviceArray.from_host(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
+        self.d_tau = None if tau is None else _lib.DeviceArray.from_host(
+            np.ascontiguousarray(tau, dtype=np.float64).reshape(-1))
+        self.W = None
+
+    def set_tau_from_parameters(self, phi, noise_std=0.0, seed=0):
+        """Synthetic measurement tau = W phi + noise, built on the device (bench / tests)."""
+        W, _ = build_regressor_device(self.robot, self.d_q, self.d_v, self.d_a, self.N, self.param, self.coupling)
+        d_phi = _lib.DeviceArray.from_host(np.ascontiguousarray(phi, dtype=np.float64))
+        d_tau = _lib.DeviceArray((W.rows,), np.float64)
+        _lib.matvec(W.buf, W.rows, W.ld, None, W.cols, d_phi, d_tau)
+        if noise_std > 0.0:
+            tau = d_tau.to_host()
+            tau += np.random.default_rng(seed).standard_normal(tau.shape[0]) * noise_std
+            d_tau = _lib.DeviceArray.from_host(tau)
+        self.d_tau = d_tau
+        W.buf.free()
+        return d_tau
+
+    # ------------------------------------------------------------------ one pass of the hot path
+    def run(self, strings=True):
+        ex = self.exchange
+        # K1 (+ fused column norms)
+        if self.W is None:
+            W, d_colsq = build_regressor_device(self.robot, self.d_q, self.d_v, self.d_a, self.N, self.param,
+                                                self.coupling, colsq=True)
+            self.W = W
+        else:  # reuse the HBM buffer across steps
+            from .tools.regressor import regressor_flags
+            mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+            W = self.W
+            d_colsq = _lib.DeviceArray((W.cols,), np.float64)
+            _lib.regressor_build(self.robot.device_model(), mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a,
+                                 W.buf, W.ld, d_colsq)
+        col_norm = ex.sum_columns(d_colsq, W.cols)
+        idx_e = [i for i in range(W.cols) if col_norm[i] < self.tol_e]
+        kept = [i for i in range(W.cols) if not col_norm[i] < self.tol_e]
+        params_r = [self.names[i] for i in kept]
+        n = len(kept)
+        # K3: TSQR over the kept columns (+ tau), then the cross-rank stack
+        with_tau = self.d_tau is not None
+        nc = n + (1 if with_tau else 0)
+        d_R = _lib.DeviceArray((nc * nc,), np.float64)
+        d_idx = _lib.DeviceArray.from_host(np.asarray(kept, dtype=np.int32))
+        _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R)
+        d_stack, count = ex.stack_triangles(d_R, nc)
+        if count > 1:
+            d_Rm = _lib.DeviceArray((nc * nc,), np.float64)
+            _lib.tsqr_merge(d_stack, count, nc, d_Rm)
+            d_R = d_Rm
+        R = np.triu(d_R.to_host().reshape(nc, nc))
+        # host tail on the n x n triangle (qrdecomposition.py:215-266)
+        idx_base, idx_regroup = qrd._select(np.diag(R)[:n], params_r, self.tol_qr)
+        R1, R2, z = qrd._regroup(R, idx_base, idx_regroup, with_tau)
+        R1_inv = np.linalg.inv(R1)
+        beta = np.around(R1_inv @ R2, 6)
+        out = {
+            "idx_e": idx_e, "params_r": params_r, "idx_base": idx_base, "beta": beta,
+            "col_norm": col_norm, "absdiagR": np.abs(np.diag(R)[:n]), "rows": W.rows * ex.world_size,
+        }
+        if strings:
+            out["params_base"] = qrd._expressions([params_r[i] for i in idx_base],
+                                                  [params_r[i] for i in idx_regroup], beta)
+        if with_tau:
+            out["phi_b"] = np.round(R1_inv @ z, 6)
+            out["phi_ls"] = R1_inv @ z
+            out["residual_norm"] = abs(R[n, n])
+        return out

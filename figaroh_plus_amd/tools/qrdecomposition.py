@@ -1,0 +1,181 @@
+"""HIP-backed mirror of ``src/figaroh/tools/qrdecomposition.py:24-332``.
+
+The reference factorises the tall matrix twice with ``np.linalg.qr`` (forming Q)
+and then only looks at R.  Here the rows of ``W_e`` are streamed once through the
+Householder TSQR kernel (``figh_tsqr``), which returns the n x n triangle (and
+``Q^T tau`` as an extra column).  The regrouped factorisation
+``qr([W1 W2])`` equals ``qr(R[:, perm])`` up to row signs, so the second QR runs
+on the permuted triangle (same kernel, one wavefront); ``beta = R1^-1 R2`` and
+``phi_b = R1^-1 Q1^T tau`` are invariant to those signs.  Selection, rounding
+and the expression strings follow the reference statement by statement.
+"""
+import numpy as np
+
+from .. import _lib
+from ..device import GpuMatrix, index_to_device, to_device, vector_to_device
+
+TOL_QR = 1e-8
+
+
+def rfactor(W, tau=None, col_idx=None, block_weight=None):
+    """Upper-triangular factor of ``[W[:, col_idx], tau]`` (rows scaled per block by ``block_weight``).
+
+    Returns an (nc, nc) array, nc = n (+1 with tau); with tau the last column holds Q^T tau and,
+    in its last entry, the residual norm of the least-squares problem.
+    """
+    Wd, _ = to_device(W)
+    if Wd.rows == 0:
+        raise ValueError("empty regressor")
+    n = Wd.cols if col_idx is None else len(col_idx)
+    d_idx = None if col_idx is None else index_to_device(col_idx)
+    d_tau = None
+    if tau is not None:
+        tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(-1)
+        if tau.shape[0] != Wd.rows:
+            raise ValueError("tau has %d entries, W has %d rows" % (tau.shape[0], Wd.rows))
+        d_tau = vector_to_device(tau)
+    nc = n + (1 if tau is not None else 0)
+    d_R = _lib.DeviceArray((nc * nc,), np.float64)
+    _lib.tsqr(Wd.buf, Wd.rows, Wd.ld, d_idx, n, d_tau, block_weight, d_R)
+    return np.triu(d_R.to_host().reshape(nc, nc))
+
+
+def _select(diagR, params_r, tol_qr):
+    assert diagR.shape[0] == len(params_r), "params_r does not have same length with R"
+    idx_base, idx_regroup = [], []
+    for i in range(len(params_r)):
+        if abs(diagR[i]) > tol_qr:
+            idx_base.append(i)
+        else:
+            idx_regroup.append(i)
+    return idx_base, idx_regroup
+
+
+def _regroup(R, idx_base, idx_regroup, with_tau):
+    """qr([W1 W2 (tau)]) from the triangle of qr([W_e (tau)]): returns (R1, R2, Q1^T tau | None)."""
+    n = len(idx_base) + len(idx_regroup)
+    perm = list(idx_base) + list(idx_regroup) + ([n] if with_tau else [])
+    R_r = rfactor(np.ascontiguousarray(R[:, perm]))
+    r = len(idx_base)
+    return R_r[:r, :r], R_r[:r, r:n], (R_r[:r, n] if with_tau else None)
+
+
+def _expressions(params_base, params_regroup, beta, tol_beta=1e-6):
+    out = list(params_base)
+    for i in range(beta.shape[0]):
+        for j in range(beta.shape[1]):
+            b = beta[i, j]
+            if abs(b) < tol_beta:
+                continue
+            if b < -tol_beta:
+                out[i] = out[i] + " - " + str(abs(b)) + "*" + str(params_regroup[j])
+            else:
+                out[i] = out[i] + " + " + str(abs(b)) + "*" + str(params_regroup[j])
+    return out
+
+
+def _base_columns(Wd, idx, keep_on_device=False):
+    out = GpuMatrix.empty(Wd.rows, len(idx))
+    if len(idx):
+        _lib.gather_cols(Wd.buf, Wd.rows, Wd.ld, index_to_device(idx), len(idx), out.buf, len(idx))
+    return out if keep_on_device else out.numpy()
+
+
+def get_baseIndex(W_e, params_r, tol_qr=TOL_QR):
+    """Indices of the linearly independent columns (qrdecomposition.py:274-296)."""
+    R = rfactor(W_e)
+    idx_base, _ = _select(np.diag(R), params_r, tol_qr)
+    return tuple(idx_base)
+
+
+def build_baseRegressor(W_e, idx_base):
+    """Columns ``idx_base`` of ``W_e`` (qrdecomposition.py:299-313)."""
+    Wd, on_dev = to_device(W_e)
+    return _base_columns(Wd, list(idx_base), on_dev)
+
+
+def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
+    """(W_b, params_base, idx_base) -- qrdecomposition.py:190-271."""
+    Wd, on_dev = to_device(W_e)
+    R = rfactor(Wd)
+    idx_base, idx_regroup = _select(np.diag(R), params_r, tol_qr)
+    R1, R2, _ = _regroup(R, idx_base, idx_regroup, False)
+    beta = np.around(np.matmul(np.linalg.inv(R1), R2), 6)
+    params_base = _expressions([params_r[i] for i in idx_base], [params_r[i] for i in idx_regroup], beta)
+    # W_b = Q1 R1 is by construction the gathered base columns (the reference asserts it, :268-269)
+    W_b = _base_columns(Wd, idx_base, on_dev)
+    return W_b, params_base, idx_base
+
+
+def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR):
+    """(W_b, base_parameters, params_base, phi_b[, phi_std]) -- qrdecomposition.py:89-187."""
+    Wd, on_dev = to_device(W_e)
+    R = rfactor(Wd, tau=tau)
+    n = len(params_r)
+    assert R.shape[0] == n + 1, "params_r does not have same length with R"
+    idx_base, idx_regroup = _select(np.diag(R)[:n], params_r, tol_qr)
+    numrank_W = len(idx_base)
+    R1, R2, q1t_tau = _regroup(R, idx_base, idx_regroup, True)
+    R1_inv = np.linalg.inv(R1)
+    beta = np.around(np.dot(R1_inv, R2), 6)
+    phi_b = np.round(np.dot(R1_inv, q1t_tau), 6)
+    W_b = _base_columns(Wd, idx_base, on_dev)
+    params_base = [params_r[i] for i in idx_base]
+    params_regroup = [params_r[i] for i in idx_regroup]
+    if params_std is not None:
+        phi_std = [params_std[x] for x in params_base]
+        for i in range(numrank_W):
+            for j in range(beta.shape[1]):
+                phi_std[i] = phi_std[i] + beta[i, j] * params_std[params_regroup[j]]
+        phi_std = np.around(phi_std, 5)
+    params_base = _expressions(params_base, params_regroup, beta)
+    base_parameters = dict(zip(params_base, phi_b))
+    if params_std is not None:
+        return W_b, base_parameters, params_base, phi_b, phi_std
+    return W_b, base_parameters, params_base, phi_b
+
+
+def QR_pivoting(tau, W_e, params_r, tol_qr=TOL_QR):
+    """(W_b, base_parameters) with column pivoting -- qrdecomposition.py:24-86.
+
+    Pivoting decisions depend only on trailing column norms, which the orthogonal reduction
+    preserves, so the pivoted factorisation is taken of the TSQR triangle.  The reference's rank
+    loop leaves ``numrank_W = 0`` when no pivot falls below ``tol_qr``; kept as is.
+    """
+    from scipy import linalg
+
+    Wd, on_dev = to_device(W_e)
+    n = len(params_r)
+    Raug = rfactor(Wd, tau=tau)
+    Q2, R, P = linalg.qr(Raug[:n, :n], pivoting=True)
+    params_rsorted = [params_r[P[i]] for i in range(P.shape[0])]
+    numrank_W = 0
+    diag = np.diag(R)
+    for i in range(diag.shape[0]):
+        if abs(diag[i]) > tol_qr:
+            continue
+        numrank_W = i
+        break
+    R1, R2 = R[:numrank_W, :numrank_W], R[:numrank_W, numrank_W:]
+    R1_inv = np.linalg.inv(R1)
+    beta = np.around(np.dot(R1_inv, R2), 6)
+    phi_b = np.round(np.dot(R1_inv, np.dot(Q2[:, :numrank_W].T, Raug[:n, n])), 6)
+    W_b = _base_columns(Wd, [int(P[i]) for i in range(numrank_W)], on_dev)
+    params_base = _expressions(params_rsorted[:numrank_W], params_rsorted[numrank_W:], beta)
+    return W_b, dict(zip(params_base, phi_b))
+
+
+def cond_num(W_b, norm_type=None):
+    """Condition number of the base regressor (qrdecomposition.py:316-332) from the singular values of
+    its TSQR triangle (identical to those of ``W_b``)."""
+    Wd, _ = to_device(W_b)
+    if norm_type == "fro":
+        if Wd.rows != Wd.cols:  # np.linalg.cond(.., 'fro') only takes square matrices
+            raise np.linalg.LinAlgError("Last 2 dimensions of the array must be square")
+        R = rfactor(Wd)
+        return np.linalg.norm(R, "fro") * np.linalg.norm(np.linalg.inv(R), "fro")
+    s = np.linalg.svd(rfactor(Wd), compute_uv=False)
+    c = s.max() / s.min()
+    if norm_type == "max_over_min_sigma":
+        return c / (1.0 / c)
+    return c

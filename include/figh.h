@@ -1,0 +1,139 @@
+/* figh.h -- C-ABI of libfigh.so: the MI355X (gfx950) regressor + QR/LS hot path of FIGAROH.
+ *
+ * The reference (thanhndv212/figaroh-plus) is pure Python and has no FFI; its boundary for this path is
+ * the set of module-level functions listed below.  Each entry point names the
+ * reference statement(s) it replaces (paths relative to the reference root).  The Python shim in
+ * figaroh_plus_amd/ binds exactly these symbols with ctypes; INTEGRATION.md shows the stub a FIGAROH
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative figh_status; figh_last_error() gives the text;
+ *   - all matrices are float64, row-major ("C order"), leading dimension in elements;
+ *   - pointers named d_* are DEVICE pointers obtained from figh_malloc (or any hipMalloc), pointers named
+ *     h_* are host pointers; buffers are caller-owned, inputs are never written;
+ *   - the library keeps one HIP stream per process (figh_stream); calls are asynchronous on it unless they
+ *     return data to the host; it is not thread-safe;
+ *   - there is NO CPU implementation behind this ABI: without a HIP device every compute entry fails
+ *     with FIGH_ERR_NO_DEVICE.
+ */
+#ifndef FIGH_H
+#define FIGH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FIGH_OK = 0,
+    FIGH_ERR_INVALID = -1,    /* bad argument (the reference would raise ValueError / AssertionError) */
+    FIGH_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error */
+    FIGH_ERR_ALLOC = -3,
+    FIGH_ERR_UNSUPPORTED = -4,
+    FIGH_ERR_COMM = -5
+} figh_status;
+
+/* joint types of figh_model_create (Pinocchio joint models reached through URDF) */
+enum { FIGH_JT_REVOLUTE = 0, FIGH_JT_PRISMATIC = 1, FIGH_JT_CONTINUOUS = 2, FIGH_JT_FREEFLYER = 3, FIGH_JT_UNIVERSE = -1 };
+/* regressor modes: param["is_joint_torques"] / param["is_external_wrench"] (regressor.py:45, :89) */
+enum { FIGH_MODE_JOINT_TORQUE = 0, FIGH_MODE_EXT_WRENCH = 1 };
+/* flags: param["has_friction"], ["has_actuator_inertia"], ["has_joint_offset"] (regressor.py:55-70, :144-169);
+ * FIGH_FLAG_TX40 appends the 3 coupling columns of add_coupling_TX40 (regressor.py:198-227);
+ * FIGH_FLAG_GENERIC forces the generic-tree kernel even when the serial-chain kernel applies (tests). */
+enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, FIGH_FLAG_TX40 = 8, FIGH_FLAG_GENERIC = 256 };
+
+typedef struct figh_model_s *figh_model_t;
+
+/* ------------------------------------------------------------------ runtime plumbing (no reference equivalent) */
+int figh_version(void);
+const char *figh_last_error(void);
+int figh_device_count(int *count);
+int figh_device_set(int device);
+int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
+int figh_malloc(void **d_ptr, size_t bytes);
+int figh_free(void *d_ptr);
+int figh_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int figh_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+int figh_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes);
+int figh_memset(void *d_dst, int value, size_t bytes);
+int figh_synchronize(void);
+/* per-kernel live timing with hipEvents on the library stream (bench.py roofline): enable, run, then query.
+ * figh_profile_get: name is the kernel family ("regressor_chain", "regressor_tree", "tsqr", "colsq", ...);
+ * returns launches and total milliseconds since the last figh_profile_reset(). */
+int figh_profile_enable(int on);
+int figh_profile_reset(void);
+int figh_profile_get(const char *name, int *launches, double *total_ms);
+
+/* ------------------------------------------------------------------ model
+ * Replaces what regressor.py reads from `robot.model` (regressor.py:36-42) and what
+ * pin.computeJointTorqueRegressor reads from the Pinocchio Model (call sites regressor.py:49-51, :93-95).
+ * Arrays have njoints entries, joint 0 = universe.  placement: 12 doubles per joint, row-major rotation (9)
+ * then translation (3), child coords -> parent coords.  body_mask[j] != 0 iff inertias[j].mass != 0
+ * (id_inertias, regressor.py:36-39).  The standard-parameter VALUES are not needed by the kernels. */
+int figh_model_create(int njoints, const int32_t *parents, const int32_t *jtype, const double *axis,
+                      const double *placement, const int32_t *idx_q, const int32_t *idx_v, const double *gravity,
+                      const int32_t *body_mask, figh_model_t *out);
+int figh_model_destroy(figh_model_t model);
+/* number of rows per sample and number of columns of the stacked regressor for (mode, flags) */
+int figh_regressor_shape(figh_model_t model, int mode, int flags, int *rows_per_sample, int *ncols);
+
+/* ------------------------------------------------------------------ K1: regressor assembly
+ * Replaces build_regressor_basic (regressor.py:20-194) and, with FIGH_FLAG_TX40, add_coupling_TX40
+ * (regressor.py:198-227): d_W[(j*N + i)*ldw + col] in the reference's joint-major row order and FIGAROH
+ * column order (14 columns per link: Ixx Ixy Ixz Iyy Iyz Izz mx my mz m Ia fv fs off).
+ * d_q: N x nq, d_v / d_a: N x nv, row-major.  ft_mask: bit c set <=> wrench component c (Fx Fy Fz Mx My Mz)
+ * is named in param["force_torque"] ('All' = 63); ignored in joint-torque mode.
+ * d_colsq (nullable): ncols doubles, receives diag(W^T W) of this call (the quantity of regressor.py:243,271). */
+int figh_regressor_build(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                         const double *d_v, const double *d_a, double *d_W, int64_t ldw, double *d_colsq);
+
+/* add_coupling_TX40 as a separate call (regressor.py:198-227), for callers that append the three columns
+ * [Iam6 fvm6 fsm6] to an existing W: d_out is (6N x 3) row-major, rows in the same joint-major order; only the
+ * rows of joints 5 and 6 are non-zero: [a6 v6 sign(v5+v6)] and [a5 v5 sign(v5+v6)].  d_v, d_a: N x nv, nv >= 6. */
+int figh_coupling_tx40(int64_t N, int nv, const double *d_v, const double *d_a, double *d_out);
+
+/* ------------------------------------------------------------------ K2: column norms / gathers / residuals
+ * figh_colsq: diag(W^T W) of a materialised matrix -- np.diag(np.dot(W.T, W)) at regressor.py:243 and :271. */
+int figh_colsq(const double *d_W, int64_t rows, int cols, int64_t ldw, double *d_out);
+/* figh_gather_cols: out[:, c] = W[:, col_idx[c]] -- np.delete(W, idx_e, 1) (regressor.py:254,292) and the
+ * column copies of build_baseRegressor / get_baseParams (qrdecomposition.py:223-236, :299-313). */
+int figh_gather_cols(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, double *d_out,
+                     int64_t ldo);
+/* figh_matvec: y = W[:, col_idx] . x  (tau_base = np.dot(W_b, phi_b), e.g. staubli_TX40/identification.py:244) */
+int figh_matvec(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_x,
+                double *d_y);
+/* figh_block_sqnorm: out[b] = sum over the b-th block of `rows/nblocks` consecutive entries of (a - b)^2;
+ * the per-joint residual norms of the WLS weights (identification_tools.py:312-315,
+ * staubli_TX40/identification.py:310-313) and the residual of relative_stdev (identification_tools.py:222). */
+int figh_block_sqnorm(const double *d_a, const double *d_b, int64_t rows, int nblocks, double *d_out);
+
+/* ------------------------------------------------------------------ K3: tall-skinny Householder QR
+ * Replaces the np.linalg.qr calls of qrdecomposition.py:105,205,238,286 for everything the reference uses
+ * them for (|diag R| rank test, R1/R2 regrouping, Q1^T tau): Householder TSQR of the gathered columns
+ * W[:, col_idx] (n of them), optionally with tau appended as one more column and with per-row-block weights
+ * (row r is scaled by h_block_weight[r / (rows/nblocks)]; NULL = unweighted) -- the weighted LS of
+ * staubli_TX40/identification.py:305-327 and identification_tools.py:317-325 is the QR of the scaled rows.
+ * d_R_out: nc x nc row-major upper triangle, nc = n + (d_tau ? 1 : 0); with tau its last column holds
+ * Q^T tau (first n entries) and the residual norm (entry nc-1).  R is defined up to row signs, like LAPACK's. */
+int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
+              const double *h_block_weight, int nblocks, double *d_R_out);
+/* Sample-sharded reduction step: QR of `count` stacked nc x nc R factors (d_Rs: count*nc x nc) into one. */
+int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out);
+
+/* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI), SURVEY.md section 8e
+ * One process per GPU.  Rank 0 calls figh_comm_unique_id and ships the 128 bytes to the other ranks by any
+ * means (the Python side uses the torch.distributed store); every rank then calls figh_comm_init. */
+int figh_comm_unique_id(void *h_id128);
+int figh_comm_init(int nranks, int rank, const void *h_id128);
+int figh_comm_destroy(void);
+/* all-gather of each rank's nc x nc R factor into d_all (nranks*nc x nc), in rank order */
+int figh_comm_allgather(const double *d_send, double *d_all, int64_t count_per_rank);
+/* in-place sum all-reduce (column norms, Gram blocks, residual norms) */
+int figh_comm_allreduce_sum(double *d_buf, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIGH_H */

@@ -1,0 +1,74 @@
+"""CPU suite, part 2: the C-ABI library loads, exports every symbol include/figh.h declares, and refuses to
+compute without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "figh.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(figh_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as entry
+    from figaroh_plus_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        entry.build()
+    return _lib
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "libfigh.so does not export %s" % name
+    assert sorted(lib.SIGNATURES) == declared, "ctypes table and include/figh.h disagree"
+
+
+def test_no_torch_or_oracle_in_product():
+    """The product path is ctypes + HIP only: no torch import at module scope, nothing from oracle/."""
+    pkg = os.path.join(ROOT, "figaroh_plus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if not fn.endswith(".py"):
+                continue
+            src = open(os.path.join(dirpath, fn)).read()
+            assert "oracle" not in src, "%s mentions the oracle" % fn
+            for line in src.splitlines():
+                if re.match(r"^(import|from)\s+torch", line):
+                    raise AssertionError("%s imports torch at module scope" % fn)
+    out = subprocess.run(["ldd", os.path.join(pkg, "libfigh.so")], capture_output=True, text=True).stdout
+    assert "torch" not in out and "oracle" not in out
+
+
+def test_compute_fails_loudly_without_gpu(lib):
+    if lib.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(lib.FighError) as e:
+        lib.DeviceArray((16,))
+    assert e.value.code == lib.ERR_NO_DEVICE
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic
+    from figaroh_plus_amd.tools.robot import Robot
+    import numpy as np
+    robot = Robot.from_flat("ur10")
+    param = {"is_joint_torques": True, "is_external_wrench": False, "has_friction": False,
+             "has_actuator_inertia": False, "has_joint_offset": False, "force_torque": None}
+    with pytest.raises(lib.FighError):
+        build_regressor_basic(robot, np.zeros((4, 6)), np.zeros((4, 6)), np.zeros((4, 6)), param)
+
+
+def test_missing_library_raises(monkeypatch, lib):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libfigh.so")
+    with pytest.raises(ImportError):
+        lib.load()

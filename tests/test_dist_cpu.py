@@ -1,0 +1,86 @@
+"""CPU suite, part 4: the N>1 path with world_size 2 over gloo -- sharding, column-norm all-reduce and the
+stack-of-triangles exchange give the single-process result (local factors come from the oracle here)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import json
+    import torch.distributed as dist
+    import oracle_c
+    from figaroh_plus_amd.dist import TorchExchange, shard_range
+    from figaroh_plus_amd.model import Model
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = TorchExchange()
+    g = np.load(os.path.join(GOLD, "cfg2_ur10.npz"))
+    flat = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", "ur10.json")).to_flat()
+    om = oracle_c.OracleModel(flat)
+    N = len(g["q_big"])
+    lo, hi = shard_range(N, rank, world)
+    W = om.build_regressor_basic(g["q_big"][lo:hi], g["v_big"][lo:hi], g["a_big"][lo:hi], 0, 0)
+    tau_full = g["tau"].reshape(6, N)
+    tau = np.ascontiguousarray(tau_full[:, lo:hi]).reshape(-1)
+    colsq = ex.allreduce_sum_host(oracle_c.colsq(W))
+    keep = [i for i in range(W.shape[1]) if not colsq[i] < 1e-6]
+    R, qtb = oracle_c.householder_r(W, keep, tau)
+    # local (n+1)x(n+1) augmented triangle, as figh_tsqr returns it
+    n = len(keep)
+    Wt = np.c_[W[:, keep], tau]
+    Raug = np.linalg.qr(Wt, mode="r")
+    stack = ex.allgather_host(Raug)
+    assert stack.shape == (world, n + 1, n + 1)
+    Rm = np.linalg.qr(stack.reshape(world * (n + 1), n + 1), mode="r")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), colsq=colsq, R=Rm, lo=lo, hi=hi)
+    ex.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_exchange_matches_single_process(tmp_path, oracle_lib):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 200, 200, 400)
+    g = np.load(os.path.join(GOLD, "cfg2_ur10.npz"))
+    assert np.array_equal(r0["colsq"], r1["colsq"])
+    assert np.abs(r0["colsq"] - g["colsq_big"]).max() <= 1e-12 * g["colsq_big"].max()
+    assert np.array_equal(r0["R"], r1["R"])  # every rank reduces the same stack -> identical triangle
+    d = np.abs(np.diag(r0["R"]))[:-1]
+    assert [i for i in range(len(d)) if d[i] > 1e-8] == list(g["idx_base"])
+    # phi from the merged triangle == single-process pinv solution
+    n = len(d)
+    idx_base = list(g["idx_base"])
+    idx_regroup = [i for i in range(n) if i not in set(idx_base)]
+    Rp = np.linalg.qr(r0["R"][:, idx_base + idx_regroup + [n]], mode="r")
+    r = len(idx_base)
+    phi = np.linalg.solve(Rp[:r, :r], Rp[:r, n])
+    assert np.abs(phi - g["phi_pinv"]).max() <= 1e-8 * np.abs(g["phi_pinv"]).max()
+
+
+def test_shard_range_partitions():
+    from figaroh_plus_amd.dist import shard_range
+    for N in (0, 1, 7, 1000, 10 ** 6 + 3):
+        for P in (1, 2, 3, 8):
+            parts = [shard_range(N, r, P) for r in range(P)]
+            assert parts[0][0] == 0 and parts[-1][1] == N
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(P - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1

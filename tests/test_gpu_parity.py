@@ -1,0 +1,298 @@
+"""GPU suite: the HIP path (through the C-ABI) against the oracle and the golden vectors.
+
+Tolerances: integer / index / string results are compared exactly; regressor entries to 1e-12 of the
+matrix scale (the reference's own inner kernel, Pinocchio, is unpinned: oracle header); parameter
+estimates to 1e-6 relative (BASELINE.json north_star) or to the reference's own 6-decimal rounding.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import oracle_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from figaroh_plus_amd import _lib
+    _lib.load()
+    assert _lib.device_count() > 0, "GPU tests need a HIP device"
+    return _lib
+
+
+def _oracle_W(g, oracle_lib, q, v, a, param=None, coupling=None):
+    om = oracle_lib.OracleModel(g.flat())
+    mode, flags, ft = oracle_lib.param_flags(param or g.param, g.coupling if coupling is None else coupling)
+    return om.build_regressor_basic(q, v, a, mode, flags, ft)
+
+
+def _gpu_W(g, q, v, a, param=None, coupling=None, generic=False):
+    from figaroh_plus_amd.tools.regressor import add_coupling_TX40, build_regressor_basic
+    robot = g.robot()
+    p = dict(param or g.param)
+    if generic:
+        p["force_generic_kernel"] = True
+    W = build_regressor_basic(robot, q, v, a, p)
+    if g.coupling if coupling is None else coupling:
+        m = robot.model
+        W = add_coupling_TX40(W, m, robot.data, len(q), m.nq, m.nv, m.njoints, q, v, a)
+    return W
+
+
+# ------------------------------------------------------------------------------------------------ K1
+def test_regressor_matches_golden(lib, golden):
+    g = golden
+    W = _gpu_W(g, g["q_small"], g["v_small"], g["a_small"])
+    ref = g["W_small"]
+    assert W.shape == ref.shape and W.dtype == np.float64
+    assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.array_equal(W == 0, ref == 0)  # structural zeros (and sign(0) = 0) are exact
+
+
+def test_generic_tree_kernel_on_chains(lib, golden):
+    if golden.name not in ("cfg1_tx40", "cfg2_ur10"):
+        pytest.skip("chain robots only")
+    g = golden
+    W = _gpu_W(g, g["q_small"], g["v_small"], g["a_small"], generic=True)
+    assert np.abs(W - g["W_small"]).max() <= 1e-12 * np.abs(g["W_small"]).max()
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 1000])
+def test_regressor_ragged_sizes(lib, golden, oracle_lib, N):
+    g = golden
+    if N == 1000 and golden.name in ("cfg3_tiago",):
+        N = 200
+    rng = np.random.default_rng(N)
+    reps = -(-N // len(g["q_big"]))
+    q = np.tile(g["q_big"], (reps, 1))[:N]
+    v = rng.uniform(-2, 2, (N, g.meta["dims"]["nv"]))
+    a = rng.uniform(-5, 5, (N, g.meta["dims"]["nv"]))
+    W = _gpu_W(g, q, v, a)
+    ref = _oracle_W(g, oracle_lib, q, v, a)
+    if g.coupling:
+        pass  # oracle flag 8 already appended the coupling columns
+    assert W.shape == ref.shape
+    assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_tx40_fused_coupling_equals_appended(lib, golden_tx40):
+    from figaroh_plus_amd.tools.regressor import build_regressor_device
+    from figaroh_plus_amd import _lib
+    g = golden_tx40
+    robot = g.robot()
+    q, v, a = g["q_small"], g["v_small"], g["a_small"]
+    dq, dv, da = (_lib.DeviceArray.from_host(np.ascontiguousarray(x).reshape(-1)) for x in (q, v, a))
+    W, colsq = build_regressor_device(robot, dq, dv, da, len(q), g.param, coupling=True, colsq=True)
+    Wh = W.numpy()
+    assert Wh.shape == (6 * len(q), 87)
+    assert np.abs(Wh - g["W_small"]).max() <= 1e-12 * np.abs(g["W_small"]).max()
+    cs = colsq.to_host()
+    ref = np.einsum("ij,ij->j", g["W_small"], g["W_small"])
+    assert np.abs(cs - ref).max() <= 1e-12 * ref.max()
+
+
+def test_external_wrench_component_selection(lib, oracle_lib):
+    from conftest import Golden
+    g = Golden("cfg5_human")
+    param = dict(g.param, force_torque=["Fx", "Mz"], has_friction=True, has_actuator_inertia=True, has_joint_offset=True)
+    q, v, a = g["q_small"], g["v_small"], g["a_small"]
+    W = _gpu_W(g, q, v, a, param=param)
+    ref = _oracle_W(g, oracle_lib, q, v, a, param=param)
+    assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
+    N = len(q)
+    assert not W[N:3 * N, :10].any() and W[:N, :10].any()
+    bad = dict(param, force_torque=["Fq"])
+    with pytest.raises(ValueError, match="Please enter valid parameters"):
+        _gpu_W(g, q, v, a, param=bad)
+
+
+def test_shape_errors(lib, golden_ur10):
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic
+    g = golden_ur10
+    with pytest.raises(ValueError):
+        build_regressor_basic(g.robot(), g["q_small"], g["v_small"][:, :5], g["a_small"], g.param)
+    W = build_regressor_basic(g.robot(), np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((0, 6)), g.param)
+    assert W.shape == (0, 84)
+
+
+# ------------------------------------------------------------------------------------------------ K2 + drop-in API
+def test_elimination_functions(lib, golden, oracle_lib):
+    from figaroh_plus_amd.tools.regressor import build_regressor_reduced, eliminate_non_dynaffect, get_index_eliminate
+    g = golden
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    idx_e, params_r = get_index_eliminate(W, g.params_std(), 1e-6)
+    assert idx_e == list(g["idx_e"]) and params_r == g.meta["params_r"]
+    W_e = build_regressor_reduced(W, idx_e)
+    assert np.array_equal(W_e, np.delete(W, idx_e, 1))
+    W_e2, params_r2 = eliminate_non_dynaffect(W, g.params_std(), 1e-6)
+    assert params_r2 == params_r and np.array_equal(W_e2, W_e)
+    # every column eliminated / none eliminated
+    assert get_index_eliminate(W, g.params_std(), 1e300)[0] == list(range(W.shape[1]))
+    assert build_regressor_reduced(W, []).shape == W.shape
+
+
+def test_base_parameters_identical(lib, golden):
+    from figaroh_plus_amd.tools.qrdecomposition import build_baseRegressor, get_baseIndex, get_baseParams
+    g = golden
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    W_e = np.delete(W, g["idx_e"], 1)
+    W_b, params_base, idx_base = get_baseParams(W_e, g.meta["params_r"], g.params_std())
+    assert idx_base == list(g["idx_base"])
+    assert params_base == g.meta["params_base"]
+    assert np.array_equal(W_b, W_e[:, idx_base])
+    assert get_baseIndex(W_e, g.meta["params_r"]) == tuple(idx_base)
+    assert np.array_equal(build_baseRegressor(W_e, tuple(idx_base)), W_b)
+    with pytest.raises(AssertionError):
+        get_baseIndex(W_e, g.meta["params_r"][:-1])
+
+
+def test_double_qr_and_sigma(lib, golden):
+    from figaroh_plus_amd.identification.identification_tools import least_squares, relative_stdev
+    from figaroh_plus_amd.tools.qrdecomposition import cond_num, double_QR
+    g = golden
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    W_e = np.delete(W, g["idx_e"], 1)
+    std = {k: float(x) for k, x in g.params_std().items()}
+    W_b, base_parameters, params_base, phi_b, phi_std = double_QR(g["tau"], W_e, g.meta["params_r"], std)
+    assert params_base == g.meta["params_base"]
+    assert list(base_parameters.keys()) == params_base
+    scale = max(1.0, np.abs(g["phi_b"]).max())
+    assert np.abs(phi_b - g["phi_b"]).max() <= 1.5e-6 * scale      # both rounded to 6 decimals
+    assert np.abs(phi_std - g["phi_std"]).max() <= 2e-5 * max(1.0, np.abs(g["phi_std"]).max())
+    assert len(double_QR(g["tau"], W_e, g.meta["params_r"])) == 4
+    phi = least_squares(W_b, g["tau"])
+    assert np.abs(phi - g["phi_pinv"]).max() <= 1e-6 * np.abs(g["phi_pinv"]).max()   # north-star tolerance
+    s = relative_stdev(W_b, g["phi_b"], g["tau"])
+    assert np.abs(s - g["std_ols"]).max() <= 0.011 + 1e-6 * np.abs(g["std_ols"]).max()
+    c = cond_num(W_b)
+    assert abs(c - g["cond_Wb"][0]) <= 1e-7 * g["cond_Wb"][0]
+    assert abs(cond_num(W_b, "max_over_min_sigma") - g["cond_Wb"][1]) <= 1e-6 * g["cond_Wb"][1]
+    with pytest.raises(np.linalg.LinAlgError):
+        cond_num(W_b, "fro")
+
+
+def test_weighted_least_squares(lib, golden):
+    from figaroh_plus_amd.identification.identification_tools import weighted_least_squares_blocks, weigthed_least_squares
+    g = golden
+    if "phi_wls_script" not in g.z.files:
+        pytest.skip("no WLS golden")
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    W_b = np.delete(W, g["idx_e"], 1)[:, g["idx_base"]]
+    nblk = g.meta["dims"]["nv"] if g.param["is_joint_torques"] else 6
+    phi, std = weighted_least_squares_blocks(W_b, g["tau"], g["phi_b"], nblk)
+    assert np.abs(phi - g["phi_wls_script"]).max() <= 1.5e-6 * max(1.0, np.abs(phi).max())
+    big = np.abs(g["std_wls_script"]) < 1e4
+    assert np.abs(std - g["std_wls_script"])[big].max() <= 0.011 + 1e-5 * np.abs(g["std_wls_script"][big]).max()
+    if "phi_wls_lib" in g.z.files:
+        n = len(g["tau"]) // nblk
+        param = dict(g.param, idx_tau_stop=[(b + 1) * n for b in range(nblk)])
+
+        class R:  # the reference reads robot.model.nq as the number of joint blocks
+            pass
+        r = R()
+        r.model = R()
+        r.model.nq = nblk
+        phi2 = weigthed_least_squares(r, g["phi_b"], W_b, g["tau"], W_b @ g["phi_b"], param)
+        assert np.abs(phi2 - g["phi_wls_lib"]).max() <= 1.5e-6 * max(1.0, np.abs(phi2).max())
+
+
+# ------------------------------------------------------------------------------------------------ K3 properties
+def test_tsqr_gram_identity_and_permutation(lib, golden):
+    from figaroh_plus_amd.tools.qrdecomposition import rfactor
+    g = golden
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    keep = [i for i in range(W.shape[1]) if i not in set(g["idx_e"].tolist())]
+    R = rfactor(W, col_idx=keep)
+    G = W[:, keep].T @ W[:, keep]
+    assert np.abs(R.T @ R - G).max() <= 1e-12 * np.abs(G).max()
+    assert np.array_equal(R, np.triu(R))
+    Wb = W[:, keep][:, g["idx_base"]]
+    Rb = rfactor(Wb)
+    ref = np.linalg.qr(Wb, mode="r")
+    assert np.abs(np.abs(np.diag(Rb)) - np.abs(np.diag(ref))).max() <= 1e-10 * np.abs(np.diag(ref)).max()
+    perm = np.random.default_rng(1).permutation(Wb.shape[0])
+    Rp = rfactor(np.ascontiguousarray(Wb[perm]))
+    assert np.abs(np.abs(Rp) - np.abs(Rb)).max() <= 1e-10 * np.abs(Rb).max()
+    # tau column: Q^T tau and the residual norm
+    Ra = rfactor(Wb, tau=g["tau"])
+    phi = np.linalg.solve(Ra[:-1, :-1], Ra[:-1, -1])
+    ref_phi, res, _, _ = np.linalg.lstsq(Wb, g["tau"], rcond=None)
+    assert np.abs(phi - ref_phi).max() <= 1e-9 * np.abs(ref_phi).max()
+    assert abs(abs(Ra[-1, -1]) - np.sqrt(res[0])) <= 1e-9 * np.sqrt(res[0])
+
+
+def test_tsqr_merge_equals_one_shot(lib, golden_ur10):
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.tools.qrdecomposition import rfactor
+    g = golden_ur10
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    keep = [i for i in range(84) if i not in set(g["idx_e"].tolist())]
+    We = np.ascontiguousarray(W[:, keep])
+    N = len(g["q_big"])
+    parts = []
+    for lo, hi in ((0, 150), (150, 400)):
+        rows = np.concatenate([np.arange(j * N + lo, j * N + hi) for j in range(6)])
+        parts.append(rfactor(np.ascontiguousarray(We[rows])))
+    d_stack = _lib.DeviceArray.from_host(np.stack(parts).reshape(-1))
+    d_R = _lib.DeviceArray((49 * 49,))
+    _lib.tsqr_merge(d_stack, 2, 49, d_R)
+    Rm = np.triu(d_R.to_host().reshape(49, 49))
+    G = We.T @ We
+    assert np.abs(Rm.T @ Rm - G).max() <= 1e-12 * np.abs(G).max()
+    d = np.abs(np.diag(Rm))
+    assert [i for i in range(49) if d[i] > 1e-8] == list(g["idx_base"])
+
+
+# ------------------------------------------------------------------------------------------------ pipeline
+def test_pipeline_matches_reference_outputs(lib, golden):
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    g = golden
+    pipe = IdentificationPipeline(g.robot(), g.param, params_std=g.params_std(), coupling=g.coupling)
+    pipe.set_samples(g["q_big"], g["v_big"], g["a_big"], g["tau"])
+    out = pipe.run()
+    assert out["idx_e"] == list(g["idx_e"])
+    assert out["params_r"] == g.meta["params_r"]
+    assert out["idx_base"] == list(g["idx_base"])
+    assert out["params_base"] == g.meta["params_base"]
+    assert np.abs(out["col_norm"] - g["colsq_big"]).max() <= 1e-12 * g["colsq_big"].max()
+    assert np.abs(out["phi_ls"] - g["phi_pinv"]).max() <= 1e-6 * np.abs(g["phi_pinv"]).max()
+    assert np.abs(out["phi_b"] - g["phi_b"]).max() <= 1.5e-6 * max(1.0, np.abs(g["phi_b"]).max())
+    out2 = pipe.run()  # second pass reuses the HBM buffers: idempotent
+    assert out2["idx_base"] == out["idx_base"] and np.array_equal(out2["phi_b"], out["phi_b"])
+
+
+@pytest.mark.parametrize("cfg,N", [("cfg2_ur10", 10 ** 6), ("cfg1_tx40", 50000)])
+def test_full_size_structural_invariants(lib, cfg, N, oracle_lib):
+    """BASELINE.json sizes: the base-parameter expressions are structural, so at 1e6 samples they must
+    be the committed strings; W . phi_urdf must equal the torque model; spot rows equal the oracle."""
+    from conftest import Golden
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    g = Golden(cfg)
+    rng = np.random.default_rng(20250410 + (2 if cfg == "cfg2_ur10" else 1))
+    qr, vr, ar = (6, 6, 6) if cfg == "cfg2_ur10" else (6, 10, 30)
+    q, v, a = rng.uniform(-qr, qr, (N, 6)), rng.uniform(-vr, vr, (N, 6)), rng.uniform(-ar, ar, (N, 6))
+    pipe = IdentificationPipeline(g.robot(), g.param, params_std=g.params_std(), coupling=g.coupling)
+    pipe.set_samples(q, v, a)
+    phi = g.phi_ref()
+    pipe.set_tau_from_parameters(phi)
+    out = pipe.run()
+    assert out["idx_e"] == list(g["idx_e"])
+    assert out["idx_base"] == list(g["idx_base"])
+    assert out["params_base"] == g.meta["params_base"]
+    # noise-free tau = W phi_ref: the identified base parameters are the regrouped standard ones
+    assert np.abs(out["phi_ls"] - g["phi_from_std"]).max() <= 1e-6 * np.abs(g["phi_from_std"]).max()
+    assert out["residual_norm"] <= 1e-9 * np.sqrt(out["rows"]) * max(1.0, np.abs(phi).max()) * 1e3
+    # spot-check 257 scattered samples of the HBM-resident W against the oracle
+    sel = rng.choice(N, 257, replace=False)
+    Wsel = _oracle_W(g, oracle_lib, q[sel], v[sel], a[sel])
+    rows = np.concatenate([j * N + sel for j in range(6)])
+    W = pipe.W
+    d_idx = _lib.DeviceArray.from_host(np.arange(W.cols, dtype=np.int32))
+    host_rows = np.empty((len(rows), W.cols))
+    for k, r in enumerate(rows):  # row gather through the ABI: d2h of one row each
+        _lib.check(_lib.load().figh_memcpy_d2h(host_rows[k].ctypes.data, W.buf.ptr + int(r) * W.ld * 8, W.cols * 8))
+    assert np.abs(host_rows - Wsel).max() <= 1e-12 * np.abs(Wsel).max()

@@ -1,0 +1,112 @@
+"""CPU suite, part 3: host-side glue of the drop-in API (no kernels involved)."""
+import io
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_np
+from conftest import ROOT
+
+
+def test_standard_parameter_names_and_values(golden):
+    robot = golden.robot()
+    with contextlib.redirect_stdout(io.StringIO()):
+        std = robot.get_standard_parameters(golden.param)
+    names = golden.meta["names_std"][:len(std)]
+    assert list(std.keys()) == names
+    ref = golden.meta["phi_ref_raw"][:len(std)]
+    assert [float(x) for x in std.values()] == [float(x) for x in ref]
+    assert list(std.values())[10] == ref[10]  # YAML strings stay strings (T40X_config.yaml:17-20 quirk)
+
+
+def test_model_attributes_mirror_pinocchio(golden):
+    robot = golden.robot()
+    m = robot.model
+    d = golden.meta["dims"]
+    assert (m.njoints, m.nq, m.nv) == (d["njoints"], d["nq"], d["nv"])
+    assert m.names == golden.meta["joint_names"]
+    assert [j for j in range(len(m.inertias.tolist())) if m.inertias.tolist()[j].mass != 0] == golden.meta["id_inertias"]
+    assert m.joints[m.njoints - 1].idx_v + m.joints[m.njoints - 1].nv == m.nv
+    assert robot.q0.shape == (m.nq,) and robot.v0.shape == (m.nv,)
+    assert m.getJointId(m.names[2]) == 2 and m.getJointId("nope") == m.njoints
+
+
+def test_flat_roundtrip(golden, tmp_path):
+    from figaroh_plus_amd.model import Model
+    m = golden.robot().model
+    p = tmp_path / "m.json"
+    m.save_flat(str(p))
+    f1, f2 = m.to_flat(), Model.from_flat(str(p)).to_flat()
+    for k in ("parents", "jtype", "idx_q", "idx_v", "axis", "placement", "mass", "lever", "inertia"):
+        assert np.array_equal(np.asarray(f1[k]), np.asarray(f2[k])), k
+
+
+def test_expression_strings_match_reference_format(golden):
+    from figaroh_plus_amd.tools import qrdecomposition as qrd
+    g = golden
+    W = oracle_np.build_regressor_basic(g.flat(), g["q_big"], g["v_big"], g["a_big"], g.param)
+    if g.coupling:
+        W = oracle_np.add_coupling_TX40(W, len(g["q_big"]), g["v_big"], g["a_big"])
+    W_e = np.delete(W, g["idx_e"], 1)
+    params_r = g.meta["params_r"]
+    res = oracle_np.base_parameters(W_e, params_r)
+    idx_base = res["idx_base"]
+    idx_regroup = [i for i in range(len(params_r)) if i not in set(idx_base)]
+    got = qrd._expressions([params_r[i] for i in idx_base], [params_r[i] for i in idx_regroup], res["beta"])
+    assert got == g.meta["params_base"]
+    ib, ir = qrd._select(res["diagR"], params_r, 1e-8)
+    assert ib == list(g["idx_base"]) and ir == idx_regroup
+    with pytest.raises(AssertionError):
+        qrd._select(res["diagR"], params_r[:-1], 1e-8)
+
+
+def test_base_param_from_standard_and_index(golden):
+    from figaroh_plus_amd.identification.identification_tools import base_param_from_standard, index_in_base_params
+    g = golden
+    std = {k: float(v) for k, v in g.params_std().items()}
+    vals = np.array(base_param_from_standard(std, g.meta["params_base"]), dtype=float)
+    assert np.allclose(vals, g["phi_from_std"], rtol=0, atol=1e-12)
+    segs = [1, 2]
+    idx = index_in_base_params(g.meta["params_base"], segs)
+    for k, seg in enumerate(segs):
+        if k in idx:
+            for ii in idx[k]:
+                assert any(tok.split("*")[-1][-len(str(seg)):] == str(seg) for tok in g.meta["params_base"][ii].split(" "))
+
+
+def test_param_from_yaml_keys(golden_ur10):
+    from figaroh_plus_amd.identification.identification_tools import get_param_from_yaml
+    import yaml
+    cfg = {"robot_params": [{"q_lim_def": 1.57, "dq_lim_def": 5.0, "fv": None, "fs": None, "Ia": None, "offset": None,
+                             "Iam6": None, "fvm6": None, "fsm6": None, "N": None, "ratio_essential": None}],
+           "problem_params": [{"is_external_wrench": False, "is_joint_torques": True, "force_torque": ["All"],
+                               "external_wrench_offsets": False, "has_friction": False, "has_joint_offset": False,
+                               "has_actuator_inertia": False, "has_coupled_wrist": False}],
+           "processing_params": [{"cut_off_frequency_butterworth": 100.0, "ts": 0.01}],
+           "tls_params": [{"mass_load": None, "which_body_loaded": None}]}
+    cfg = yaml.safe_load(yaml.safe_dump(cfg))
+    param = get_param_from_yaml(golden_ur10.robot(), cfg)
+    ref = golden_ur10.param
+    assert set(param) == set(ref)
+    assert param["nb_samples"] == ref["nb_samples"] == 100
+    for k in ("is_joint_torques", "has_friction", "force_torque", "ts"):
+        assert param[k] == ref[k]
+
+
+def test_regressor_flags_and_errors(golden):
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.tools.regressor import regressor_flags
+    mode, flags, ft = regressor_flags(golden.param, golden.coupling)
+    assert mode == (0 if golden.param["is_joint_torques"] else 1)
+    assert bool(flags & _lib.FLAG_FRICTION) == bool(golden.param["has_friction"])
+    assert bool(flags & _lib.FLAG_TX40) == golden.coupling
+    bad = dict(golden.param, is_joint_torques=False, is_external_wrench=True, force_torque=["Fx", "bogus"])
+    with pytest.raises(ValueError, match="Please enter valid parameters"):
+        regressor_flags(bad)
+    ok = dict(bad, force_torque=["Fx", "Mz"])
+    assert regressor_flags(ok)[2] == (1 | 32)
+    neither = dict(golden.param, is_joint_torques=False, is_external_wrench=False)
+    with pytest.raises(UnboundLocalError):
+        regressor_flags(neither)

@@ -1,0 +1,109 @@
+"""CPU suite, part 1: the oracle against the golden vectors produced by the reference's own code."""
+import json
+import os
+
+import numpy as np
+
+import oracle_np
+from conftest import GOLD
+
+
+def test_numpy_oracle_reproduces_reference_W(golden):
+    g = golden
+    W = oracle_np.build_regressor_basic(g.flat(), g["q_small"], g["v_small"], g["a_small"], g.param)
+    if g.coupling:
+        W = oracle_np.add_coupling_TX40(W, len(g["q_small"]), g["v_small"], g["a_small"])
+    assert W.shape == g["W_small"].shape
+    assert np.array_equal(W, g["W_small"])  # same arithmetic, same order -> bit-exact
+
+
+def test_c_oracle_matches_reference_W(golden, oracle_lib):
+    g = golden
+    om = oracle_lib.OracleModel(g.flat())
+    mode, flags, ft = oracle_lib.param_flags(g.param, g.coupling)
+    W = om.build_regressor_basic(g["q_small"], g["v_small"], g["a_small"], mode, flags, ft)
+    scale = np.abs(g["W_small"]).max()
+    assert np.abs(W - g["W_small"]).max() <= 1e-14 * scale * 50
+    # sign(0) == 0 on the zero-velocity sample (regressor.py:57)
+    zero_rows = np.where(np.all(g["v_small"] == 0, axis=1))[0]
+    assert len(zero_rows) == 1
+
+
+def test_regressor_times_urdf_parameters_is_rnea(golden):
+    """Independent physics known-answer: Y(q,v,a) . phi_urdf == RNEA(q,v,a)."""
+    g = golden
+    flat = g.flat()
+    phi = oracle_np.dynamic_parameters(flat).ravel()
+    tau = g["Y_sample1"] @ phi
+    assert np.abs(tau - g["rnea_sample1"]).max() <= 1e-10 * max(1.0, np.abs(tau).max())
+    q, v, a = g["q_small"][2], g["v_small"][2], g["a_small"][2]
+    Y = oracle_np.joint_torque_regressor(flat, q, v, a)
+    assert np.abs(Y @ phi - oracle_np.rnea(flat, q, v, a)).max() <= 1e-10 * max(1.0, np.abs(Y @ phi).max())
+
+
+def test_elimination_and_base_parameters_match_reference(golden, oracle_lib):
+    g = golden
+    om = oracle_lib.OracleModel(g.flat())
+    mode, flags, ft = oracle_lib.param_flags(g.param, g.coupling)
+    W = om.build_regressor_basic(g["q_big"], g["v_big"], g["a_big"], mode, flags, ft)
+    cs = oracle_lib.colsq(W)
+    assert np.abs(cs - g["colsq_big"]).max() <= 1e-12 * cs.max()
+    idx_e, params_r = oracle_np.get_index_eliminate(W, g.meta["names_std"], 1e-6)
+    assert idx_e == list(g["idx_e"])
+    assert params_r == g.meta["params_r"]
+    W_e = np.delete(W, idx_e, 1)
+    res = oracle_np.base_parameters(W_e, params_r, tau=g["tau"])
+    assert res["idx_base"] == list(g["idx_base"])
+    assert res["params_base"] == g.meta["params_base"]
+    assert np.abs(res["phi_b"] - g["phi_b"]).max() <= 2e-6 * max(1.0, np.abs(g["phi_b"]).max())
+    # C Householder: same rank decision
+    keep = [i for i in range(W.shape[1]) if i not in set(idx_e)]
+    R = oracle_lib.householder_r(W, keep)
+    d = np.abs(np.diag(R))
+    assert [i for i in range(len(keep)) if d[i] > 1e-8] == list(g["idx_base"])
+
+
+def test_sigma_and_wls_restatements(golden):
+    g = golden
+    if "phi_wls_script" not in g.z.files:
+        return
+    flat = g.flat()
+    W = oracle_np.build_regressor_basic(flat, g["q_big"], g["v_big"], g["a_big"], g.param)
+    if g.coupling:
+        W = oracle_np.add_coupling_TX40(W, len(g["q_big"]), g["v_big"], g["a_big"])
+    keep = [i for i in range(W.shape[1]) if i not in set(g["idx_e"].tolist())]
+    W_b = W[:, keep][:, g["idx_base"]]
+    std = oracle_np.relative_stdev(W_b, g["phi_b"], g["tau"])
+    assert np.allclose(std, g["std_ols"], rtol=0, atol=0.011)
+    nblk = g.meta["dims"]["nv"] if g.param["is_joint_torques"] else 6
+    n = len(g["tau"]) // nblk
+    phi, s = oracle_np.wls_script(W_b, g["tau"], g["phi_b"], [n] * nblk)
+    assert np.abs(phi - g["phi_wls_script"]).max() <= 2e-6 * max(1.0, np.abs(phi).max())
+    if "phi_wls_lib" in g.z.files:
+        stops = [(b + 1) * n for b in range(nblk)]
+        phi2 = oracle_np.weigthed_least_squares(nblk, g["phi_b"], W_b, g["tau"], W_b @ g["phi_b"], stops)
+        assert np.abs(phi2 - g["phi_wls_lib"]).max() <= 2e-6 * max(1.0, np.abs(phi2).max())
+
+
+def test_tx40_committed_expressions_reproduced(golden_tx40):
+    """Known-answer list held by the reference: examples/staubli_TX40/results/TX40_bp_5.csv column 0.
+    The current reference code emits the same 60 strings plus 'Ia6' (SURVEY.md section 4)."""
+    with open(os.path.join(GOLD, "tx40_bp_5_expressions.json")) as f:
+        gold = json.load(f)["expressions"]
+    mine = golden_tx40.meta["params_base"]
+    assert len(gold) == 60 and len(mine) == 61
+    assert [p for p in mine if p != "Ia6"] == gold
+
+
+def test_model_anchors(golden):
+    """Structural anchors of SURVEY.md appendix A.4."""
+    d = golden.meta["dims"]
+    expect = {"cfg1_tx40": (7, 6, 6, 87, 76, 61), "cfg2_ur10": (7, 6, 6, 84, 49, 36),
+              "cfg3_tiago": (25, 34, 24, 336, 240, 179), "cfg4_talos": (34, 39, 38, 462, 330, 234),
+              "cfg5_human": (41, 46, 45, 560, 190, 164)}[golden.name]
+    assert (d["njoints"], d["nq"], d["nv"], d["cols"], d["kept"], d["base"]) == expect
+    if golden.name == "cfg5_human":
+        assert golden.meta["id_inertias"] == [1, 4, 5, 7, 9, 12, 15, 16, 19, 21, 23, 26, 27, 30, 32, 34, 37, 38, 40]
+    if golden.name == "cfg2_ur10":
+        assert golden.meta["params_base"][0] == ("Izz1 + 1.0*Iyy2 + 1.0*Iyy3 + 0.375401*m3 + 1.0*Iyy4 + 0.3483*mz4"
+                                                " + 0.732399*m4 + 0.732399*m5 + 0.732399*m6")
