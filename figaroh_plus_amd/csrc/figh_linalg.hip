@@ -48,20 +48,26 @@ __global__ __launch_bounds__(64) void tsqr_kernel(const double *__restrict__ W, 
     __shared__ double Rl[RLDS ? 64 * 64 : 1];
     double *Rg = Rws + wave * (long)nc * nc;  // private triangle; also the working copy when !RLDS
 
-    int kind[CPL];
-    long coff[CPL];
+    // per-lane column sources: W[:, col_idx[col]] (stride ldw), tau (stride 1) or nothing.  Loads are
+    // unconditional (clamped row, select afterwards) so a tile's M loads are all in flight together.
+    const double *src[CPL];
+    long stride[CPL];
+    bool live[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const int col = lane + 64 * c;
         if (col < n) {
-            kind[c] = 1;
-            coff[c] = col_idx ? col_idx[col] : col;
+            src[c] = W + (col_idx ? col_idx[col] : col);
+            stride[c] = ldw;
+            live[c] = true;
         } else if (col == n && tau != nullptr) {
-            kind[c] = 2;
-            coff[c] = 0;
+            src[c] = tau;
+            stride[c] = 1;
+            live[c] = true;
         } else {
-            kind[c] = 0;
-            coff[c] = 0;
+            src[c] = W;
+            stride[c] = 0;
+            live[c] = false;
         }
     }
     if constexpr (RLDS) {
@@ -74,17 +80,17 @@ __global__ __launch_bounds__(64) void tsqr_kernel(const double *__restrict__ W, 
     }
     __syncthreads();
 
-    for (long r0 = rbeg; r0 < rend; r0 += M) {
-        double B[CPL][M];
+    auto load_tile = [&](double (&T)[CPL][M], const long r0) {
         long blk = blkw ? r0 / rows_per_blk : 0;
         long next_blk = (blk + 1) * rows_per_blk;
 #pragma unroll
         for (int r = 0; r < M; ++r) {
             const long row = r0 + r;
             const bool inb = row < rend;
+            const long rowc = inb ? row : rend - 1;
             double scale = 1.0;
-            if (blkw && inb) {
-                if (row >= next_blk) {
+            if (blkw) {
+                if (rowc >= next_blk) {
                     ++blk;
                     next_blk += rows_per_blk;
                 }
@@ -92,14 +98,15 @@ __global__ __launch_bounds__(64) void tsqr_kernel(const double *__restrict__ W, 
             }
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                double x = 0.0;
-                if (inb) {
-                    if (kind[c] == 1) x = W[row * ldw + coff[c]] * scale;
-                    else if (kind[c] == 2) x = tau[row] * scale;
-                }
-                B[c][r] = x;
+                const double x = src[c][rowc * stride[c]];
+                T[c][r] = (inb && live[c]) ? x * scale : 0.0;
             }
         }
+    };
+
+    for (long r0 = rbeg; r0 < rend; r0 += M) {
+        double B[CPL][M];
+        load_tile(B, r0);
         int kstart = nc;
 #pragma unroll
         for (int c = CPL - 1; c >= 0; --c) {
@@ -417,7 +424,7 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     if (!Rws) return FIGH_ERR_ALLOC;
     long nw = 0;
     {
-        ProfileScope scope("tsqr");
+        ProfileScope scope(rows >= 65536 ? "tsqr" : "tsqr_small");
         if (int rc = tsqr_level(d_W, rows, ldw, d_col_idx, n, d_tau, d_blkw, rows_per_blk, nc, target, 64, Rws, &nw))
             return rc;
     }

@@ -281,10 +281,23 @@ def test_full_size_structural_invariants(lib, cfg, N, oracle_lib):
     pipe.set_tau_from_parameters(phi)
     out = pipe.run()
     assert out["idx_e"] == list(g["idx_e"])
-    assert out["idx_base"] == list(g["idx_base"])
-    assert out["params_base"] == g.meta["params_base"]
-    # noise-free tau = W phi_ref: the identified base parameters are the regrouped standard ones
-    assert np.abs(out["phi_ls"] - g["phi_from_std"]).max() <= 1e-6 * np.abs(g["phi_from_std"]).max()
+    if cfg == "cfg2_ur10":
+        assert out["idx_base"] == list(g["idx_base"])
+        assert out["params_base"] == g.meta["params_base"]
+        # noise-free tau = W phi_ref: the identified base parameters are the regrouped standard ones
+        assert np.abs(out["phi_ls"] - g["phi_from_std"]).max() <= 1e-6 * np.abs(g["phi_from_std"]).max()
+    else:
+        # TX40 at the script's 50 000 samples: one structurally dependent pivot is a genuine tiny number that
+        # grows like sqrt(N) (2.5e-9 at N=400, 2.7e-8 here) and crosses TOL_QR=1e-8, so the REFERENCE's own
+        # np.linalg.qr keeps 62 columns at this size.  Parity = the same decision as LAPACK on the same rows.
+        W_ref = _oracle_W(g, oracle_lib, q, v, a)
+        keep = [i for i in range(W_ref.shape[1]) if i not in set(out["idx_e"])]
+        d = np.abs(np.diag(np.linalg.qr(W_ref[:, keep], mode="r")))
+        ref_base = [i for i in range(len(keep)) if d[i] > 1e-8]
+        assert len(ref_base) == 62
+        assert out["idx_base"] == ref_base
+        dep = [i for i in range(len(keep)) if i not in set(ref_base)]
+        assert out["absdiagR"][dep].max() < 1e-9 and out["absdiagR"][ref_base].min() > 1e-8
     assert out["residual_norm"] <= 1e-9 * np.sqrt(out["rows"]) * max(1.0, np.abs(phi).max()) * 1e3
     # spot-check 257 scattered samples of the HBM-resident W against the oracle
     sel = rng.choice(N, 257, replace=False)
