@@ -211,12 +211,19 @@ __global__ __launch_bounds__(256) void colsq_kernel(const double *__restrict__ W
     }
 }
 
-__global__ void reduce_cols_kernel(const double *__restrict__ part, int nblocks, int ncols, double *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const double *__restrict__ part, int nblocks, int ncols,
+                                                          double *__restrict__ out) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long)b * ncols + c];
-    out[c] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long)b * ncols + c];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sm[0];
 }
 
 __global__ __launch_bounds__(256) void gather_cols_kernel(const double *__restrict__ W, long rows, long ldw,
@@ -351,7 +358,7 @@ int figh_colsq(const double *d_W, int64_t rows, int cols, int64_t ldw, double *d
     ProfileScope scope("colsq");
     hipLaunchKernelGGL(colsq_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream(), d_W, (long)rows, cols, (long)ldw,
                        rpb, part);
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3((cols + 127) / 128), dim3(128), 0, stream(), part, (int)nblocks, cols,
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(cols), dim3(256), 0, stream(), part, (int)nblocks, cols,
                        d_out);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;

@@ -236,17 +236,39 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
                 }
             }
             if constexpr (COLSQ) {
-                if (lane < NC) {
-                    for (int r = 0; r < nvalid; ++r) {
-                        const double x0 = tile[r * LDT + lane];
-                        cs0 += x0 * x0;
+                // thread `lane` owns columns lane and lane+64: sum of squares down the tile (LDS reads pipelined)
+                if (nvalid == 64) {
+                    if (lane < NC) {
+                        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 64; r += 4) {
+                            const double x0 = tile[r * LDT + lane], x1 = tile[(r + 1) * LDT + lane];
+                            const double x2 = tile[(r + 2) * LDT + lane], x3 = tile[(r + 3) * LDT + lane];
+                            t0 += x0 * x0;
+                            t1 += x1 * x1;
+                            t2 += x2 * x2;
+                            t3 += x3 * x3;
+                        }
+                        cs0 += (t0 + t1) + (t2 + t3);
                     }
-                }
-                if (lane + 64 < NC) {
-                    for (int r = 0; r < nvalid; ++r) {
-                        const double x1 = tile[r * LDT + lane + 64];
-                        cs1 += x1 * x1;
+                    if (lane + 64 < NC) {
+                        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 64; r += 4) {
+                            const double x0 = tile[r * LDT + lane + 64], x1 = tile[(r + 1) * LDT + lane + 64];
+                            const double x2 = tile[(r + 2) * LDT + lane + 64], x3 = tile[(r + 3) * LDT + lane + 64];
+                            t0 += x0 * x0;
+                            t1 += x1 * x1;
+                            t2 += x2 * x2;
+                            t3 += x3 * x3;
+                        }
+                        cs1 += (t0 + t1) + (t2 + t3);
                     }
+                } else {
+                    if (lane < NC)
+                        for (int r = 0; r < nvalid; ++r) cs0 += tile[r * LDT + lane] * tile[r * LDT + lane];
+                    if (lane + 64 < NC)
+                        for (int r = 0; r < nvalid; ++r) cs1 += tile[r * LDT + lane + 64] * tile[r * LDT + lane + 64];
                 }
             }
             __syncthreads();
@@ -259,14 +281,20 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
     }
 }
 
-// partial[b][c] -> out[c], fixed summation order (deterministic)
-__global__ void reduce_partials_kernel(const double *__restrict__ part, int nblocks, int ncols,
-                                       double *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
+// partial[b][c] -> out[c]: one workgroup per column, strided partial sums + LDS tree (fixed order: deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ part, int nblocks, int ncols,
+                                                              double *__restrict__ out) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long)b * ncols + c];
-    out[c] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long)b * ncols + c];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sm[0];
 }
 
 // ---------------------------------------------------------------------------------------------- tree kernel
@@ -537,7 +565,7 @@ static int launch_chain(const figh_model_s *m, int flags, long N, const double *
         if (!part) return FIGH_ERR_ALLOC;
         hipLaunchKernelGGL((regressor_chain_kernel<NJ, TX40, true>), dim3((unsigned)grid), dim3(64), lds, stream(), P,
                            flags, N, q, v, a, W, ldw, vec_ok, part);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((G::NC + 127) / 128), dim3(128), 0, stream(), part, (int)grid,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(G::NC), dim3(256), 0, stream(), part, (int)grid,
                            G::NC, d_colsq);
     } else {
         hipLaunchKernelGGL((regressor_chain_kernel<NJ, TX40, false>), dim3((unsigned)grid), dim3(64), lds, stream(), P,
