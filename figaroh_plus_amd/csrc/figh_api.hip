@@ -19,6 +19,18 @@ struct ProfileAcc {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 static std::map<std::string, ProfileAcc> g_prof;
+static std::vector<hipEvent_t> g_event_pool;  // events are recycled: creating one costs far more than recording it
+
+static hipEvent_t acquire_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
 
 static void *g_ws[8] = {nullptr};
 static size_t g_ws_bytes[8] = {0};
@@ -60,7 +72,9 @@ void *workspace(size_t bytes, int slot) {
 
 ProfileScope::ProfileScope(const char *name) : name_(name) {
     if (!g_profile) return;
-    if (hipEventCreate(&e0_) != hipSuccess || hipEventCreate(&e1_) != hipSuccess) return;
+    e0_ = acquire_event();
+    e1_ = acquire_event();
+    if (!e0_ || !e1_) return;
     (void)hipEventRecord(e0_, g_stream);
 }
 
@@ -79,8 +93,8 @@ static void drain_profile() {
                 kv.second.ms += ms;
                 kv.second.launches += 1;
             }
-            (void)hipEventDestroy(p.first);
-            (void)hipEventDestroy(p.second);
+            g_event_pool.push_back(p.first);
+            g_event_pool.push_back(p.second);
         }
         kv.second.pending.clear();
     }

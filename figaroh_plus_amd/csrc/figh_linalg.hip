@@ -19,6 +19,8 @@
 // fp64 on gfx950: v_mfma_f64_16x16x4 and the fp64 VALU FMA have the SAME peak (78.6 TFLOP/s), so for n ~ 50
 // (a 16-wide Householder panel would leave the matrix pipe waiting on the panel's reductions) the wave-level
 // VALU formulation is used; the roofline this kernel is priced against is that fp64 peak.
+#include <cstdlib>
+
 #include "figh_internal.h"
 
 namespace figh {
@@ -32,6 +34,219 @@ __device__ __forceinline__ double bcast_s(double x, int src_lane) {  // wave-uni
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
     return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tsqr2_kernel<NCC, NRC>: the n <= 16*NCC (<= 80) kernel.  The 16*NRC x 16*NCC tile sits in registers in the
+// MFMA f64 C/D layout: lane = 16*g + c holds rows 16*rc + g + 4*reg, column 16*cc + c.  A column step then needs
+//   - the pivot column inside each row group: DPP row_newbcast (a VALU mov, no LDS crossbar),
+//   - the dot products summed over the four row groups: v_permlane32_swap / v_permlane16_swap (gfx950) + add,
+// instead of 128 ds_bpermute per step (6.2 cycles each per CU, shared by the four SIMDs).  Column chunks are
+// ROTATED after each 16-column panel so the pivot panel is always register slot 0 (keeps the unrolled step code
+// at 16 variants); finished chunks drop out of the update loops (the triangle's zero part costs nothing).
+template <int K>
+__device__ __forceinline__ double row_bcast(double x) {  // value of lane-column K of my row group
+    // v_mov_b64_dpp: gfx90a+ allows 64-bit DPP for row_newbcast, one instruction per double
+    return __longlong_as_double(
+        __builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(x), 0x150 + K, 0xf, 0xf, false));
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double allreduce_rowgroups(double x) {  // sum over lanes c, c+16, c+32, c+48
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    u32x2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    u32x2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(y);
+    hi = __double2hiint(y);
+    a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double uniform_of(double x) {  // SGPR copy of a value that is identical in all lanes
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
+template <int NCC, int NRC>
+struct Tsqr2State {
+    static constexpr int RPL = 4 * NRC;  // rows per lane
+    double T[NCC][RPL];
+    double *Rl;   // LDS triangle, row stride LDR
+    int lane_c;   // lane & 15
+    int lane_g;   // lane >> 4
+    int nc;
+};
+
+template <int KK, int NCC, int NRC>
+__device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p, const int live) {
+    constexpr int RPL = 4 * NRC, LDR = 16 * NCC;
+    const int kabs = 16 * p + KK;
+    double x[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) x[i] = row_bcast<KK>(S.T[0][i]);
+    double d[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        d[cc] = 0.0;
+        if (cc < live) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; i += 2) {
+                s0 += x[i] * S.T[cc][i];
+                s1 += x[i + 1] * S.T[cc][i + 1];
+            }
+            d[cc] = allreduce_rowgroups(s0 + s1);
+        }
+    }
+    const double sigma = uniform_of(row_bcast<KK>(d[0]));
+    if (sigma == 0.0) return;  // pivot column already zero below the triangle: H = I (LAPACK dlarfg)
+    double Rk[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) Rk[cc] = cc < live ? S.Rl[kabs * LDR + 16 * (p + cc) + S.lane_c] : 0.0;
+    const double alpha = uniform_of(row_bcast<KK>(Rk[0]));
+    // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
+    // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds + Newton steps instead of the
+    // IEEE sqrt and two divisions (a 250-cycle dependent chain per column otherwise)
+    const double q2 = fma(alpha, alpha, sigma);
+    double rs = __builtin_amdgcn_rsq(q2);
+    rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
+    rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
+    double sq = q2 * rs;
+    sq = fma(fma(-sq, sq, q2), 0.5 * rs, sq);
+    const double dsum = fabs(alpha) + sq;
+    double ri = __builtin_amdgcn_rcp(dsum);
+    ri = ri * fma(-dsum, ri, 2.0);
+    ri = ri * fma(-dsum, ri, 2.0);
+    const double beta = -copysign(sq, alpha);
+    const double inv = copysign(ri, alpha);
+    const double tfac = dsum * rs;
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        if (cc < live) {
+            const bool trail = cc > 0 || S.lane_c > KK;
+            const double wj = trail ? (Rk[cc] + d[cc] * inv) * tfac : 0.0;
+            const double cj = wj * inv;
+            const double rnew = (cc == 0 && S.lane_c == KK) ? beta : Rk[cc] - wj;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) S.T[cc][i] -= cj * x[i];
+            if (S.lane_g == 0) S.Rl[kabs * LDR + 16 * (p + cc) + S.lane_c] = rnew;
+        }
+    }
+}
+
+template <int NCC, int NRC>
+__global__ __launch_bounds__(64) void tsqr2_kernel(const double *__restrict__ W, const long rows, const long ldw,
+                                                   const int *__restrict__ col_idx, const int n,
+                                                   const double *__restrict__ tau, const double *__restrict__ blkw,
+                                                   const long rows_per_blk, const long rows_per_wave,
+                                                   double *__restrict__ Rws, const int nc, const int dbg) {
+    constexpr int RPL = 4 * NRC, M = 16 * NRC, LDR = 16 * NCC;
+    extern __shared__ __attribute__((aligned(16))) double Rl[];  // nc x LDR
+    const int lane = threadIdx.x;
+    const long wave = blockIdx.x;
+    // Tiles are dealt round-robin (tile t -> wave t mod nwaves): in the joint-major row order the number of
+    // non-zero leading columns, hence the work per tile, depends on the joint block, and contiguous ranges
+    // would leave the waves of the last joints idle while those of joint 1 finish.
+    const long ntiles = (rows + 16 * NRC - 1) / (16 * NRC);
+    const long tstep = gridDim.x;
+    const long rend = rows;
+    (void)rows_per_wave;
+    Tsqr2State<NCC, NRC> S;
+    S.Rl = Rl;
+    S.lane_c = lane & 15;
+    S.lane_g = lane >> 4;
+    S.nc = nc;
+    const int np = (nc + 15) >> 4;  // panels
+
+    const double *src[NCC];
+    long stride[NCC];
+    bool livecol[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        const int col = 16 * cc + S.lane_c;
+        if (col < n) {
+            src[cc] = W + (col_idx ? col_idx[col] : col);
+            stride[cc] = ldw;
+            livecol[cc] = true;
+        } else if (col == n && tau != nullptr) {
+            src[cc] = tau;
+            stride[cc] = 1;
+            livecol[cc] = true;
+        } else {
+            src[cc] = W;
+            stride[cc] = 0;
+            livecol[cc] = false;
+        }
+    }
+    for (int e = lane; e < nc * LDR; e += 64) Rl[e] = 0.0;
+    __syncthreads();
+
+    // Raw tile loads: lane (g, c) takes rows r0 + 16 rc + g + 4 reg.  Unconditional clamped loads with no dependent
+    // instruction, so all 16*NCC requests of a tile are in flight at once; the NEXT tile is requested before the
+    // current one is factored (software prefetch: one wave per SIMD hides HBM latency by itself).
+    double Tn[NCC][RPL];
+    auto request_tile = [&](const long r0) {
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const long row = r0 + 16 * (i >> 2) + S.lane_g + 4 * (i & 3);
+                const long rowc = row < rend ? row : rend - 1;
+                Tn[cc][i] = (dbg & 2) ? 1.0 + (double)(cc * RPL + i + lane) : src[cc][rowc * stride[cc]];
+            }
+    };
+    if (wave < ntiles) request_tile(wave * M);
+
+    for (long t = wave; t < ntiles; t += tstep) {
+        const long r0 = t * M;
+        // ---- take delivery of the requested tile: row masking, optional row-block weights, zero-column map
+        unsigned long long nzlo = 0;  // bit col (<64) set <=> column has a non-zero in this tile
+        unsigned nzhi = 0;            // cols 64..79
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+            bool nz = false;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const long row = r0 + 16 * (i >> 2) + S.lane_g + 4 * (i & 3);
+                const bool inb = row < rend;
+                double scale = 1.0;
+                if (blkw) scale = blkw[(inb ? row : rend - 1) / rows_per_blk];
+                const double val = (inb && livecol[cc]) ? Tn[cc][i] * scale : 0.0;
+                S.T[cc][i] = val;
+                nz |= (val != 0.0);
+            }
+            const unsigned long long b = __ballot(nz);
+            const unsigned m16 = (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);
+            if (cc < 4) nzlo |= (unsigned long long)m16 << (16 * cc);
+            else nzhi |= m16 << (16 * (cc - 4));
+        }
+        if (t + tstep < ntiles) request_tile((t + tstep) * M);
+        int first_nz = nc;
+        if (nzlo) first_nz = __ffsll((long long)nzlo) - 1;
+        else if (nzhi) first_nz = 64 + __ffs((int)nzhi) - 1;
+
+        for (int p = 0; p < ((dbg & 1) ? 0 : np); ++p) {
+            const int live = NCC - p;
+            if (16 * p + 15 >= first_nz) {
+#define FIGH_STEP(KK)                                                                     \
+    if (16 * p + KK >= first_nz && 16 * p + KK < nc) tsqr2_step<KK, NCC, NRC>(S, p, live);
+                FIGH_STEP(0) FIGH_STEP(1) FIGH_STEP(2) FIGH_STEP(3) FIGH_STEP(4) FIGH_STEP(5) FIGH_STEP(6) FIGH_STEP(7)
+                FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
+#undef FIGH_STEP
+            }
+            // rotate: the next panel becomes slot 0
+#pragma unroll
+            for (int cc = 0; cc + 1 < NCC; ++cc)
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) S.T[cc][i] = S.T[cc + 1][i];
+        }
+    }
+    __syncthreads();
+    double *Rg = Rws + wave * (long)nc * nc;
+    for (int e = lane; e < nc * nc; e += 64) {
+        const int k = e / nc, col = e - k * nc;
+        Rg[e] = Rl[k * LDR + col];
+    }
 }
 
 template <int CPL, int M, bool RLDS>
@@ -282,6 +497,9 @@ static int cu_count() {
     return cus;
 }
 
+static const bool g_force_v1 = getenv("FIGH_TSQR_V1") != nullptr;
+static const int g_dbg = getenv("FIGH_TSQR_DBG") ? atoi(getenv("FIGH_TSQR_DBG")) : 0;  // ablation: 1 no factor, 2 no loads  // A/B switch: round-1 bpermute kernel
+
 // one TSQR level: rows of (W, ldw) -> nw triangles in Rws.  Returns nw (>0) or a negative status.
 static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
                        const double *d_blkw, long rows_per_blk, int nc, long target_waves, long align,
@@ -299,7 +517,13 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
 #define FIGH_TSQR_LAUNCH(CPL, MM, RL)                                                                          \
     hipLaunchKernelGGL((tsqr_kernel<CPL, MM, RL>), grid, block, 0, stream(), W, rows, ldw, col_idx, n, tau,     \
                        d_blkw, rows_per_blk, rpw, Rws_out, nc)
-    if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
+    if (nc <= 64 && !g_force_v1) {
+        hipLaunchKernelGGL((tsqr2_kernel<4, 4>), grid, block, sizeof(double) * nc * 64, stream(), W, rows, ldw, col_idx, n,
+                           tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
+    } else if (nc <= 80 && !g_force_v1) {
+        hipLaunchKernelGGL((tsqr2_kernel<5, 4>), grid, block, sizeof(double) * nc * 80, stream(), W, rows, ldw, col_idx, n,
+                           tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
+    } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
     else if (nc <= 128) FIGH_TSQR_LAUNCH(2, 32, false);
     else if (nc <= 256) FIGH_TSQR_LAUNCH(4, 16, false);
     else if (nc <= 384) FIGH_TSQR_LAUNCH(6, 16, false);
@@ -424,7 +648,16 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
         rows_per_blk = rows / nblocks;
     }
     // level 0: one wave per SIMD for the register-resident n <= 64 kernel, fewer for the wide ones
-    long target = nc <= 64 ? cu_count() * 4L : cu_count() * 2L;
+    long target = cu_count() * 2L;
+    if (nc <= 80 && !g_force_v1) {  // register-tile kernel: as many waves per CU as its LDS triangle admits
+        const size_t lds = sizeof(double) * nc * (nc <= 64 ? 64 : 80);
+        long per_cu = (long)((160 * 1024) / lds);
+        if (per_cu > 4) per_cu = 4;  // tile + prefetched tile in registers: one wave per SIMD
+        if (per_cu < 1) per_cu = 1;
+        target = cu_count() * per_cu;
+    } else if (nc <= 64) {
+        target = cu_count() * 4L;
+    }
     const size_t tri = sizeof(double) * (size_t)nc * nc;
     long nw_est = target + 1;
     double *Rws = static_cast<double *>(workspace(tri * nw_est, 5));

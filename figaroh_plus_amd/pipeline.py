@@ -75,17 +75,21 @@ class IdentificationPipeline:
     def run(self, strings=True):
         ex = self.exchange
         # K1 (+ fused column norms)
-        if self.W is None:
-            W, d_colsq = build_regressor_device(self.robot, self.d_q, self.d_v, self.d_a, self.N, self.param,
-                                                self.coupling, colsq=True)
-            self.W = W
-        else:  # reuse the HBM buffer across steps
-            from .tools.regressor import regressor_flags
-            mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
-            W = self.W
-            d_colsq = _lib.DeviceArray((W.cols,), np.float64)
-            _lib.regressor_build(self.robot.device_model(), mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a,
-                                 W.buf, W.ld, d_colsq)
+        from .tools.regressor import regressor_flags
+        mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+        handle = self.robot.device_model()
+        if self.W is None:  # HBM buffers are allocated once and reused by every step
+            rows_per_sample, ncols = handle.shape(mode, flags)
+            self.W = GpuMatrix.empty(rows_per_sample * self.N, ncols)
+            cap = ncols + 1
+            self._d_colsq = _lib.DeviceArray((ncols,), np.float64)
+            self._d_idx = _lib.DeviceArray((cap,), np.int32)
+            self._d_R = _lib.DeviceArray((cap * cap,), np.float64)
+            self._d_Rm = _lib.DeviceArray((cap * cap,), np.float64)
+            self._d_Rp = _lib.DeviceArray((cap * cap,), np.float64)
+            self._d_R2 = _lib.DeviceArray((cap * cap,), np.float64)
+        W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
+        _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         col_norm = ex.sum_columns(d_colsq, W.cols)
         idx_e = [i for i in range(W.cols) if col_norm[i] < self.tol_e]
         kept = [i for i in range(W.cols) if not col_norm[i] < self.tol_e]
@@ -94,18 +98,28 @@ class IdentificationPipeline:
         # K3: TSQR over the kept columns (+ tau), then the cross-rank stack
         with_tau = self.d_tau is not None
         nc = n + (1 if with_tau else 0)
-        d_R = _lib.DeviceArray((nc * nc,), np.float64)
-        d_idx = _lib.DeviceArray.from_host(np.asarray(kept, dtype=np.int32))
+        d_R, d_idx = self._d_R, self._d_idx
+        kept_i32 = np.asarray(kept, dtype=np.int32)
+        _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
         _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R)
         d_stack, count = ex.stack_triangles(d_R, nc)
         if count > 1:
-            d_Rm = _lib.DeviceArray((nc * nc,), np.float64)
-            _lib.tsqr_merge(d_stack, count, nc, d_Rm)
-            d_R = d_Rm
-        R = np.triu(d_R.to_host().reshape(nc, nc))
-        # host tail on the n x n triangle (qrdecomposition.py:215-266)
+            _lib.tsqr_merge(d_stack, count, nc, self._d_Rm)
+            d_R = self._d_Rm
+        R = np.empty((nc, nc))
+        _lib.check(lib.figh_memcpy_d2h(R.ctypes.data, d_R.ptr, R.nbytes))
+        R = np.triu(R)
+        # tail on the n x n triangle (qrdecomposition.py:215-266): selection on the host, the regrouped
+        # factorisation qr(R[:, perm]) again through the TSQR kernel (gather + one wavefront)
         idx_base, idx_regroup = qrd._select(np.diag(R)[:n], params_r, self.tol_qr)
-        R1, R2, z = qrd._regroup(R, idx_base, idx_regroup, with_tau)
+        perm = np.asarray(list(idx_base) + list(idx_regroup) + ([n] if with_tau else []), dtype=np.int32)
+        _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, perm.ctypes.data, perm.nbytes))
+        _lib.gather_cols(d_R, nc, nc, d_idx, nc, self._d_Rp, nc)
+        _lib.tsqr(self._d_Rp, nc, nc, None, nc, None, None, self._d_R2)
+        R_r = np.empty((nc, nc))
+        _lib.check(lib.figh_memcpy_d2h(R_r.ctypes.data, self._d_R2.ptr, R_r.nbytes))
+        r = len(idx_base)
+        R1, R2, z = R_r[:r, :r], R_r[:r, r:n], (R_r[:r, n] if with_tau else None)
         R1_inv = np.linalg.inv(R1)
         beta = np.around(R1_inv @ R2, 6)
         out = {
