@@ -79,8 +79,9 @@ struct Tsqr2State {
 
 template <int KK, int NCC, int NRC>
 __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p, const int live) {
-    constexpr int RPL = 4 * NRC, LDR = 16 * NCC;
-    const int kabs = 16 * p + KK;
+    constexpr int RPL = 4 * NRC;
+    // packed triangle: panel p keeps 16 rows of 16*(NCC-p) entries (columns 16p ..), see tsqr2_rbase
+    const int rowoff = 256 * (p * NCC - (p * (p - 1)) / 2) + KK * 16 * (NCC - p);
     double x[RPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i) x[i] = row_bcast<KK>(S.T[0][i]);
@@ -102,7 +103,7 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p,
     if (sigma == 0.0) return;  // pivot column already zero below the triangle: H = I (LAPACK dlarfg)
     double Rk[NCC];
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) Rk[cc] = cc < live ? S.Rl[kabs * LDR + 16 * (p + cc) + S.lane_c] : 0.0;
+    for (int cc = 0; cc < NCC; ++cc) Rk[cc] = cc < live ? S.Rl[rowoff + 16 * cc + S.lane_c] : 0.0;
     const double alpha = uniform_of(row_bcast<KK>(Rk[0]));
     // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
     // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds + Newton steps instead of the
@@ -129,19 +130,19 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p,
             const double rnew = (cc == 0 && S.lane_c == KK) ? beta : Rk[cc] - wj;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) S.T[cc][i] -= cj * x[i];
-            if (S.lane_g == 0) S.Rl[kabs * LDR + 16 * (p + cc) + S.lane_c] = rnew;
+            if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = rnew;
         }
     }
 }
 
-template <int NCC, int NRC>
-__global__ __launch_bounds__(64) void tsqr2_kernel(const double *__restrict__ W, const long rows, const long ldw,
+template <int NCC, int NRC, bool PF>
+__global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__restrict__ W, const long rows, const long ldw,
                                                    const int *__restrict__ col_idx, const int n,
                                                    const double *__restrict__ tau, const double *__restrict__ blkw,
                                                    const long rows_per_blk, const long rows_per_wave,
                                                    double *__restrict__ Rws, const int nc, const int dbg) {
     constexpr int RPL = 4 * NRC, M = 16 * NRC, LDR = 16 * NCC;
-    extern __shared__ __attribute__((aligned(16))) double Rl[];  // nc x LDR
+    extern __shared__ __attribute__((aligned(16))) double Rl[];  // packed triangle, tsqr2_lds_doubles(nc) entries
     const int lane = threadIdx.x;
     const long wave = blockIdx.x;
     // Tiles are dealt round-robin (tile t -> wave t mod nwaves): in the joint-major row order the number of
@@ -178,27 +179,53 @@ __global__ __launch_bounds__(64) void tsqr2_kernel(const double *__restrict__ W,
             livecol[cc] = false;
         }
     }
-    for (int e = lane; e < nc * LDR; e += 64) Rl[e] = 0.0;
+    {
+        const int npan = (nc + 15) >> 4;
+        const int tot = 256 * (npan * NCC - (npan * (npan - 1)) / 2);
+        for (int e = lane; e < tot; e += 64) Rl[e] = 0.0;
+    }
     __syncthreads();
 
     // Raw tile loads: lane (g, c) takes rows r0 + 16 rc + g + 4 reg.  Unconditional clamped loads with no dependent
     // instruction, so all 16*NCC requests of a tile are in flight at once; the NEXT tile is requested before the
     // current one is factored (software prefetch: one wave per SIMD hides HBM latency by itself).
+    // Full tiles use a wave-uniform row base (SGPR pair) + a 32-bit per-lane element offset g*ldw + column, so the
+    // 16*NCC requests need NCC address registers instead of 16*NCC 64-bit pointers; tau is fetched at delivery.
+    int loff[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        const int col = 16 * cc + S.lane_c;
+        loff[cc] = col < n ? (int)(S.lane_g * ldw) + (col_idx ? col_idx[col] : col) : 0;
+    }
+    const bool small_ld = ldw < (1L << 28);
     double Tn[NCC][RPL];
     auto request_tile = [&](const long r0) {
+        if (small_ld && r0 + M <= rend && !(dbg & 2)) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double *rowbase = W + (r0 + 16 * (i >> 2) + 4 * (i & 3)) * ldw;
+#pragma unroll
+                for (int cc = 0; cc < NCC; ++cc) Tn[cc][i] = rowbase[loff[cc]];
+            }
+            return;
+        }
 #pragma unroll
         for (int cc = 0; cc < NCC; ++cc)
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const long row = r0 + 16 * (i >> 2) + S.lane_g + 4 * (i & 3);
                 const long rowc = row < rend ? row : rend - 1;
-                Tn[cc][i] = (dbg & 2) ? 1.0 + (double)(cc * RPL + i + lane) : src[cc][rowc * stride[cc]];
+                Tn[cc][i] = (dbg & 2) ? 1.0 + (double)(cc * RPL + i + lane)
+                                      : (stride[cc] == 1 ? 0.0 : src[cc][rowc * stride[cc]]);
             }
     };
-    if (wave < ntiles) request_tile(wave * M);
+    if constexpr (PF) {
+        if (wave < ntiles) request_tile(wave * M);
+    }
 
     for (long t = wave; t < ntiles; t += tstep) {
         const long r0 = t * M;
+        if constexpr (!PF) request_tile(r0);  // two waves per SIMD: the other wave's factorisation hides this latency
         // ---- take delivery of the requested tile: row masking, optional row-block weights, zero-column map
         unsigned long long nzlo = 0;  // bit col (<64) set <=> column has a non-zero in this tile
         unsigned nzhi = 0;            // cols 64..79
@@ -211,7 +238,9 @@ __global__ __launch_bounds__(64) void tsqr2_kernel(const double *__restrict__ W,
                 const bool inb = row < rend;
                 double scale = 1.0;
                 if (blkw) scale = blkw[(inb ? row : rend - 1) / rows_per_blk];
-                const double val = (inb && livecol[cc]) ? Tn[cc][i] * scale : 0.0;
+                double raw = Tn[cc][i];
+                if (stride[cc] == 1 && !(dbg & 2)) raw = src[cc][inb ? row : rend - 1];  // the tau lane-column
+                const double val = (inb && livecol[cc]) ? raw * scale : 0.0;
                 S.T[cc][i] = val;
                 nz |= (val != 0.0);
             }
@@ -220,7 +249,9 @@ __global__ __launch_bounds__(64) void tsqr2_kernel(const double *__restrict__ W,
             if (cc < 4) nzlo |= (unsigned long long)m16 << (16 * cc);
             else nzhi |= m16 << (16 * (cc - 4));
         }
-        if (t + tstep < ntiles) request_tile((t + tstep) * M);
+        if constexpr (PF) {
+            if (t + tstep < ntiles) request_tile((t + tstep) * M);
+        }
         int first_nz = nc;
         if (nzlo) first_nz = __ffsll((long long)nzlo) - 1;
         else if (nzhi) first_nz = 64 + __ffs((int)nzhi) - 1;
@@ -240,6 +271,261 @@ __global__ __launch_bounds__(64) void tsqr2_kernel(const double *__restrict__ W,
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) S.T[cc][i] = S.T[cc + 1][i];
         }
+    }
+    __syncthreads();
+    double *Rg = Rws + wave * (long)nc * nc;
+    for (int e = lane; e < nc * nc; e += 64) {
+        const int k = e / nc, col = e - k * nc;
+        const int pk = k >> 4;
+        Rg[e] = col < 16 * pk ? 0.0
+                              : Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (k & 15) * 16 * (NCC - pk) + (col - 16 * pk)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tsqr3_kernel<NCC>: blocked Householder (compact WY) on the same register tile.  A 16-column panel is factored
+// with the DPP / permlane step above restricted to the panel itself; its 16 reflectors are then applied to every
+// trailing 16-column chunk as three v_mfma_f64_16x16x4_f64 contractions
+//        G  = R_pt + V^T B      (16 MFMA, A = V and B = the tile chunk, both straight from the tile registers:
+//                                the f64 C/D layout row = g + 4 reg IS the A/B operand layout of K-slice `reg`)
+//        Wm = T^T G             ( 4 MFMA)
+//        R_pt -= Wm,  B -= V Wm (16 MFMA, V transposed once per panel through 8.7 KB of LDS)
+// T is built column by column during the panel from the Gram entries v_c^T v_k, which the panel's own dot
+// products already deliver for the finished columns c < k (T^-1 = striu(V^T V) + diag(1/tau), LAPACK larft).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+
+template <int NCC>
+struct Tsqr3State {
+    f64x4 T[NCC][4];   // [col chunk][row chunk]: lane (g, c) holds rows 16 rc + g + 4 r, column 16 cc + c
+    double Trow[16];   // row c of the current panel's T factor
+    double myinv;      // 1 / (alpha - beta) of reflector c
+    int lane_c, lane_g;
+};
+
+// sum over the finished reflectors m < KK of T[c][m] * vg(lane-column m): DPP lane selects must be immediates
+template <int M0, int KK>
+struct TColumn {
+    static __device__ __forceinline__ double dot(const double *Trow, const double vg) {
+        return fma(Trow[M0], row_bcast<M0>(vg), TColumn<M0 + 1, KK>::dot(Trow, vg));
+    }
+};
+template <int KK>
+struct TColumn<KK, KK> {
+    static __device__ __forceinline__ double dot(const double *, const double) { return 0.0; }
+};
+
+// one column step of panel P (pivot = lane-column KK of chunk P); Rrow = LDS row 16P+KK from column 16P on
+template <int P, int KK, int NCC>
+__device__ __forceinline__ void tsqr3_step(Tsqr3State<NCC> &S, double *__restrict__ Rrow) {
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = row_bcast<KK>(S.T[P][i >> 2][i & 3]);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        s0 += x[i] * S.T[P][i >> 2][i & 3];
+        s1 += x[i + 1] * S.T[P][(i + 1) >> 2][(i + 1) & 3];
+    }
+    const double d = allreduce_rowgroups(s0 + s1);
+    const double sigma = uniform_of(row_bcast<KK>(d));
+    if (sigma == 0.0) return;  // H = I: T row/column KK and V column KK stay zero
+    const double rk = Rrow[S.lane_c];
+    const double alpha = uniform_of(row_bcast<KK>(rk));
+    const double q2 = fma(alpha, alpha, sigma);
+    double rs = __builtin_amdgcn_rsq(q2);
+    rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
+    rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
+    double sq = q2 * rs;
+    sq = fma(fma(-sq, sq, q2), 0.5 * rs, sq);
+    const double dsum = fabs(alpha) + sq;
+    double ri = __builtin_amdgcn_rcp(dsum);
+    ri = ri * fma(-dsum, ri, 2.0);
+    ri = ri * fma(-dsum, ri, 2.0);
+    const double beta = -copysign(sq, alpha);
+    const double inv = copysign(ri, alpha);
+    const double tfac = dsum * rs;
+    const bool trail = S.lane_c > KK;
+    const double wj = trail ? (rk + d * inv) * tfac : 0.0;
+    const double cj = wj * inv;
+    if (S.lane_g == 0) Rrow[S.lane_c] = (S.lane_c == KK) ? beta : rk - wj;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S.T[P][i >> 2][i & 3] -= cj * x[i];
+    // Gram entry v_c^T v_KK of the finished columns c < KK, then column KK of T
+    const double vg = (S.lane_c < KK) ? d * S.myinv * inv : 0.0;
+    if (S.lane_c == KK) S.myinv = inv;
+    const double acc = TColumn<0, KK>::dot(S.Trow, vg);  // sum_{m<KK} T[c][m] * (v_m^T v_KK)
+    S.Trow[KK] = (S.lane_c < KK) ? -tfac * acc : ((S.lane_c == KK) ? tfac : 0.0);
+}
+
+// panel P of the current tile: factor chunk P, then apply its reflectors to chunks P+1 .. np-1 with MFMA
+template <int P, int NCC>
+__device__ __forceinline__ void tsqr3_panel(Tsqr3State<NCC> &S, double *__restrict__ Rl, double *__restrict__ Vl,
+                                            double *__restrict__ Tl, const int first_nz, const int nc, const int np) {
+    constexpr int LDR = 16 * NCC, LDV = 17;
+    if (16 * P + 15 < first_nz || 16 * P >= nc) return;  // all 16 columns zero in this tile, or padding: H = I
+    const int c = S.lane_c, g = S.lane_g;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S.Trow[i] = 0.0;
+    S.myinv = 0.0;
+    double *Rdiag = Rl + (16 * P) * LDR + 16 * P;
+#define FIGH_STEP3(KK) \
+    if (16 * P + KK >= first_nz && 16 * P + KK < nc) tsqr3_step<P, KK, NCC>(S, Rdiag + KK * LDR);
+    FIGH_STEP3(0) FIGH_STEP3(1) FIGH_STEP3(2) FIGH_STEP3(3) FIGH_STEP3(4) FIGH_STEP3(5) FIGH_STEP3(6) FIGH_STEP3(7)
+    FIGH_STEP3(8) FIGH_STEP3(9) FIGH_STEP3(10) FIGH_STEP3(11) FIGH_STEP3(12) FIGH_STEP3(13) FIGH_STEP3(14)
+    FIGH_STEP3(15)
+#undef FIGH_STEP3
+    if constexpr (P + 1 < NCC) {
+        if (P + 1 >= np) return;  // no trailing chunk holds real columns
+        // ---- V = X diag(inv), in place (chunk P is finished): A operand of V^T B as is; -V goes transposed through
+        // LDS for B -= V Wm; T goes through LDS to become the A operand of T^T G
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double vv = S.T[P][i >> 2][i & 3] * S.myinv;
+            S.T[P][i >> 2][i & 3] = vv;
+            Vl[(16 * (i >> 2) + g + 4 * (i & 3)) * LDV + c] = -vv;
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) Tl[c * 16 + m] = S.Trow[m];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = P + 1; cc < NCC; ++cc) {
+            if (cc < np) {
+                double Tt[4], Vt[4][4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    Tt[s] = Tl[(4 * s + g) * 16 + c];
+#pragma unroll
+                    for (int rc = 0; rc < 4; ++rc) Vt[rc][s] = Vl[(16 * rc + c) * LDV + 4 * s + g];
+                }
+                f64x4 Rpt, G0, G1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Rpt[r] = Rl[(16 * P + g + 4 * r) * LDR + 16 * cc + c];
+                G0 = Rpt;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(S.T[P][i >> 2][i & 3], S.T[cc][i >> 2][i & 3], G0, 0, 0, 0);
+                    G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(S.T[P][(i + 1) >> 2][(i + 1) & 3],
+                                                              S.T[cc][(i + 1) >> 2][(i + 1) & 3], G1, 0, 0, 0);
+                }
+                const f64x4 G = G0 + G1;
+                f64x4 Wm = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Wm = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt[s], G[s], Wm, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Rl[(16 * P + g + 4 * r) * LDR + 16 * cc + c] = Rpt[r] - Wm[r];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int rc = 0; rc < 4; ++rc)
+                        S.T[cc][rc] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[rc][s], Wm[s], S.T[cc][rc], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NCC, bool PF>
+__global__ __launch_bounds__(64) void tsqr3_kernel(const double *__restrict__ W, const long rows, const long ldw,
+                                                   const int *__restrict__ col_idx, const int n,
+                                                   const double *__restrict__ tau, const double *__restrict__ blkw,
+                                                   const long rows_per_blk, double *__restrict__ Rws, const int nc,
+                                                   const int dbg) {
+    constexpr int M = 64, LDR = 16 * NCC, LDV = 17;
+    extern __shared__ __attribute__((aligned(16))) double lds3[];
+    double *Rl = lds3;                 // nc x LDR
+    double *Vl = lds3 + nc * LDR;      // 64 x LDV: -V, row-major
+    double *Tl = Vl + 64 * LDV;        // 16 x 16: T, row-major
+    const int lane = threadIdx.x;
+    const long wave = blockIdx.x;
+    const long ntiles = (rows + M - 1) / M;
+    const long tstep = gridDim.x;
+    const long rend = rows;
+    Tsqr3State<NCC> S;
+    S.lane_c = lane & 15;
+    S.lane_g = lane >> 4;
+    const int c = S.lane_c, g = S.lane_g;
+    const int np = (dbg & 1) ? 0 : (nc + 15) >> 4;
+
+    const double *src[NCC];
+    long stride[NCC];
+    bool livecol[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        const int col = 16 * cc + c;
+        if (col < n) {
+            src[cc] = W + (col_idx ? col_idx[col] : col);
+            stride[cc] = ldw;
+            livecol[cc] = true;
+        } else if (col == n && tau != nullptr) {
+            src[cc] = tau;
+            stride[cc] = 1;
+            livecol[cc] = true;
+        } else {
+            src[cc] = W;
+            stride[cc] = 0;
+            livecol[cc] = false;
+        }
+    }
+    for (int e = lane; e < nc * LDR; e += 64) Rl[e] = 0.0;
+    __syncthreads();
+
+    // raw loads of a tile (no dependent instruction: all 16*NCC requests in flight together)
+    double Tn[NCC][16];
+    auto request_tile = [&](const long r0) {
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long row = r0 + 16 * (i >> 2) + g + 4 * (i & 3);
+                const long rowc = row < rend ? row : rend - 1;
+                Tn[cc][i] = (dbg & 2) ? 1.0 + (double)(cc * 16 + i + lane) : src[cc][rowc * stride[cc]];
+            }
+    };
+    if constexpr (PF) {
+        if (wave < ntiles) request_tile(wave * M);
+    }
+
+    for (long t = wave; t < ntiles; t += tstep) {
+        const long r0 = t * M;
+        if constexpr (!PF) request_tile(r0);
+        unsigned long long nzlo = 0;
+        unsigned nzhi = 0;
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+            bool nz = false;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long row = r0 + 16 * (i >> 2) + g + 4 * (i & 3);
+                const bool inb = row < rend;
+                double scale = 1.0;
+                if (blkw) scale = blkw[(inb ? row : rend - 1) / rows_per_blk];
+                const double val = (inb && livecol[cc]) ? Tn[cc][i] * scale : 0.0;
+                S.T[cc][i >> 2][i & 3] = val;
+                nz |= (val != 0.0);
+            }
+            const unsigned long long b = __ballot(nz);
+            const unsigned m16 = (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);
+            if (cc < 4) nzlo |= (unsigned long long)m16 << (16 * cc);
+            else nzhi |= m16 << (16 * (cc - 4));
+        }
+        int first_nz = nc;
+        if (nzlo) first_nz = __ffsll((long long)nzlo) - 1;
+        else if (nzhi) first_nz = 64 + __ffs((int)nzhi) - 1;
+
+        // Panels are unrolled at compile time, so the register allocator sees that only chunk NCC-1 is alive
+        // during the last panel: the next tile is requested there (software prefetch into the freed registers;
+        // one wave per SIMD cannot rely on other waves to hide HBM latency).
+        tsqr3_panel<0, NCC>(S, Rl, Vl, Tl, first_nz, nc, np);
+        if constexpr (NCC > 2) tsqr3_panel<1, NCC>(S, Rl, Vl, Tl, first_nz, nc, np);
+        if constexpr (NCC > 3) tsqr3_panel<2, NCC>(S, Rl, Vl, Tl, first_nz, nc, np);
+        if constexpr (NCC > 4) tsqr3_panel<3, NCC>(S, Rl, Vl, Tl, first_nz, nc, np);
+        if constexpr (PF) {
+            if (t + tstep < ntiles) request_tile((t + tstep) * M);
+        }
+        tsqr3_panel<NCC - 1, NCC>(S, Rl, Vl, Tl, first_nz, nc, np);
     }
     __syncthreads();
     double *Rg = Rws + wave * (long)nc * nc;
@@ -497,8 +783,15 @@ static int cu_count() {
     return cus;
 }
 
+// A/B switches (within-run comparisons).  Default: tsqr2 (unblocked DPP/permlane kernel, 2 waves per SIMD, no
+// register prefetch) -- measured fastest: 2.29 ms vs 2.98 ms with register prefetch at 1 wave/SIMD, 3.44 ms for the
+// blocked MFMA kernel tsqr3 (1 wave/SIMD: its column steps are a ~1000-cycle dependent chain that only a second
+// wave can fill), 10.0 ms for the round-1 ds_bpermute kernel.  FIGH_TSQR_V1 / FIGH_TSQR_V3 select the others,
+// FIGH_TSQR_PF the register-prefetch variants, FIGH_TSQR_DBG ablates (1 = no factorisation, 2 = no loads).
 static const bool g_force_v1 = getenv("FIGH_TSQR_V1") != nullptr;
-static const int g_dbg = getenv("FIGH_TSQR_DBG") ? atoi(getenv("FIGH_TSQR_DBG")) : 0;  // ablation: 1 no factor, 2 no loads  // A/B switch: round-1 bpermute kernel
+static const bool g_force_v2 = getenv("FIGH_TSQR_V3") == nullptr;
+static const bool g_pf = getenv("FIGH_TSQR_PF") != nullptr;
+static const int g_dbg = getenv("FIGH_TSQR_DBG") ? atoi(getenv("FIGH_TSQR_DBG")) : 0;
 
 // one TSQR level: rows of (W, ldw) -> nw triangles in Rws.  Returns nw (>0) or a negative status.
 static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
@@ -517,12 +810,31 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
 #define FIGH_TSQR_LAUNCH(CPL, MM, RL)                                                                          \
     hipLaunchKernelGGL((tsqr_kernel<CPL, MM, RL>), grid, block, 0, stream(), W, rows, ldw, col_idx, n, tau,     \
                        d_blkw, rows_per_blk, rpw, Rws_out, nc)
-    if (nc <= 64 && !g_force_v1) {
-        hipLaunchKernelGGL((tsqr2_kernel<4, 4>), grid, block, sizeof(double) * nc * 64, stream(), W, rows, ldw, col_idx, n,
-                           tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
+    const size_t lds3_extra = sizeof(double) * (64 * 17 + 16 * 16);  // -V^T staging + T of the blocked kernel
+    if (nc <= 64 && !g_force_v1 && !g_force_v2) {
+        if (g_pf)
+            hipLaunchKernelGGL((tsqr3_kernel<4, true>), grid, block, sizeof(double) * nc * 64 + lds3_extra, stream(), W,
+                               rows, ldw, col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg);
+        else
+            hipLaunchKernelGGL((tsqr3_kernel<4, false>), grid, block, sizeof(double) * nc * 64 + lds3_extra, stream(), W,
+                               rows, ldw, col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg);
+    } else if (nc <= 80 && !g_force_v1 && !g_force_v2) {
+        hipLaunchKernelGGL((tsqr3_kernel<5, false>), grid, block, sizeof(double) * nc * 80 + lds3_extra, stream(), W, rows,
+                           ldw, col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg);
+    } else if (nc <= 64 && !g_force_v1) {
+        const int npan = (nc + 15) >> 4;
+        const size_t lds2 = sizeof(double) * 256 * (npan * 4 - (npan * (npan - 1)) / 2);
+        if (g_pf)
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
+                               d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
+        else
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
+                               d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
     } else if (nc <= 80 && !g_force_v1) {
-        hipLaunchKernelGGL((tsqr2_kernel<5, 4>), grid, block, sizeof(double) * nc * 80, stream(), W, rows, ldw, col_idx, n,
-                           tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
+        const int npan = (nc + 15) >> 4;
+        const size_t lds2 = sizeof(double) * 256 * (npan * 5 - (npan * (npan - 1)) / 2);
+        hipLaunchKernelGGL((tsqr2_kernel<5, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau, d_blkw,
+                           rows_per_blk, rpw, Rws_out, nc, g_dbg);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
     else if (nc <= 128) FIGH_TSQR_LAUNCH(2, 32, false);
     else if (nc <= 256) FIGH_TSQR_LAUNCH(4, 16, false);
@@ -650,10 +962,14 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     // level 0: one wave per SIMD for the register-resident n <= 64 kernel, fewer for the wide ones
     long target = cu_count() * 2L;
     if (nc <= 80 && !g_force_v1) {  // register-tile kernel: as many waves per CU as its LDS triangle admits
-        const size_t lds = sizeof(double) * nc * (nc <= 64 ? 64 : 80);
-        long per_cu = (long)((160 * 1024) / lds);
-        if (per_cu > 4) per_cu = 4;  // tile + prefetched tile in registers: one wave per SIMD
-        if (per_cu < 1) per_cu = 1;
+        long per_cu = 4;  // tile + prefetched tile in registers: one wave per SIMD
+        if (nc <= 64 && g_force_v2 && !g_pf) {
+            // unblocked kernel capped at 256 registers: two waves per SIMD when the packed LDS triangles fit
+            const int npan = (nc + 15) >> 4;
+            const size_t lds = sizeof(double) * 256 * (npan * 4 - (npan * (npan - 1)) / 2);
+            per_cu = (long)((160 * 1024) / lds);
+            if (per_cu > 8) per_cu = 8;
+        }
         target = cu_count() * per_cu;
     } else if (nc <= 64) {
         target = cu_count() * 4L;
