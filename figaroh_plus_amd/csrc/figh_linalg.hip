@@ -77,14 +77,16 @@ struct Tsqr2State {
     int nc;
 };
 
-template <int KK, int NCC, int NRC>
+// TRI: the tile is one upper-triangular R factor (merge levels): rows 16 rc .. are zero in the columns of panels
+// p < rc, so row chunks rc > p take no part in panel p (neither in the pivot column nor in the update).
+template <int KK, int NCC, int NRC, bool TRI>
 __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p, const int live) {
     constexpr int RPL = 4 * NRC;
     // packed triangle: panel p keeps 16 rows of 16*(NCC-p) entries (columns 16p ..), see tsqr2_rbase
     const int rowoff = 256 * (p * NCC - (p * (p - 1)) / 2) + KK * 16 * (NCC - p);
     double x[RPL];
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) x[i] = row_bcast<KK>(S.T[0][i]);
+    for (int i = 0; i < RPL; ++i) x[i] = (!TRI || (i >> 2) <= p) ? row_bcast<KK>(S.T[0][i]) : 0.0;
     double d[NCC];
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc) {
@@ -93,8 +95,10 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p,
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; i += 2) {
-                s0 += x[i] * S.T[cc][i];
-                s1 += x[i + 1] * S.T[cc][i + 1];
+                if (!TRI || (i >> 2) <= p) {
+                    s0 += x[i] * S.T[cc][i];
+                    s1 += x[i + 1] * S.T[cc][i + 1];
+                }
             }
             d[cc] = allreduce_rowgroups(s0 + s1);
         }
@@ -129,18 +133,22 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p,
             const double cj = wj * inv;
             const double rnew = (cc == 0 && S.lane_c == KK) ? beta : Rk[cc] - wj;
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) S.T[cc][i] -= cj * x[i];
+            for (int i = 0; i < RPL; ++i)
+                if (!TRI || (i >> 2) <= p) S.T[cc][i] -= cj * x[i];
             if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = rnew;
         }
     }
 }
 
-template <int NCC, int NRC, bool PF>
+template <int NCC, int NRC, bool PF, bool TRI>
 __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__restrict__ W, const long rows, const long ldw,
                                                    const int *__restrict__ col_idx, const int n,
                                                    const double *__restrict__ tau, const double *__restrict__ blkw,
                                                    const long rows_per_blk, const long rows_per_wave,
-                                                   double *__restrict__ Rws, const int nc, const int dbg) {
+                                                   double *__restrict__ Rws, const int nc, const int dbg,
+                                                   const int out_rows) {
+    // out_rows: row stride of the triangles written to Rws (nc = compact; 64 = one zero-padded R per 64-row tile,
+    // the input format of the TRI merge levels)
     constexpr int RPL = 4 * NRC, M = 16 * NRC, LDR = 16 * NCC;
     extern __shared__ __attribute__((aligned(16))) double Rl[];  // packed triangle, tsqr2_lds_doubles(nc) entries
     const int lane = threadIdx.x;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
             const int live = NCC - p;
             if (16 * p + 15 >= first_nz) {
 #define FIGH_STEP(KK)                                                                     \
-    if (16 * p + KK >= first_nz && 16 * p + KK < nc) tsqr2_step<KK, NCC, NRC>(S, p, live);
+    if (16 * p + KK >= first_nz && 16 * p + KK < nc) tsqr2_step<KK, NCC, NRC, TRI>(S, p, live);
                 FIGH_STEP(0) FIGH_STEP(1) FIGH_STEP(2) FIGH_STEP(3) FIGH_STEP(4) FIGH_STEP(5) FIGH_STEP(6) FIGH_STEP(7)
                 FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
 #undef FIGH_STEP
@@ -273,12 +281,13 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
         }
     }
     __syncthreads();
-    double *Rg = Rws + wave * (long)nc * nc;
-    for (int e = lane; e < nc * nc; e += 64) {
+    double *Rg = Rws + wave * (long)out_rows * nc;
+    for (int e = lane; e < out_rows * nc; e += 64) {
         const int k = e / nc, col = e - k * nc;
         const int pk = k >> 4;
-        Rg[e] = col < 16 * pk ? 0.0
-                              : Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (k & 15) * 16 * (NCC - pk) + (col - 16 * pk)];
+        Rg[e] = (k >= nc || col < 16 * pk)
+                    ? 0.0
+                    : Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (k & 15) * 16 * (NCC - pk) + (col - 16 * pk)];
     }
 }
 
@@ -796,7 +805,8 @@ static const int g_dbg = getenv("FIGH_TSQR_DBG") ? atoi(getenv("FIGH_TSQR_DBG"))
 // one TSQR level: rows of (W, ldw) -> nw triangles in Rws.  Returns nw (>0) or a negative status.
 static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
                        const double *d_blkw, long rows_per_blk, int nc, long target_waves, long align,
-                       double *Rws_out, long *nw_out) {
+                       double *Rws_out, long *nw_out, int out_rows = 0, bool tri = false) {
+    if (out_rows == 0) out_rows = nc;
     int M;
     if (nc <= 64) M = 64;
     else if (nc <= 128) M = 32;
@@ -824,17 +834,20 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
     } else if (nc <= 64 && !g_force_v1) {
         const int npan = (nc + 15) >> 4;
         const size_t lds2 = sizeof(double) * 256 * (npan * 4 - (npan * (npan - 1)) / 2);
-        if (g_pf)
-            hipLaunchKernelGGL((tsqr2_kernel<4, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
-                               d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
+        if (tri)
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
+                               tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
+        else if (g_pf)
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, true, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
+                               tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
         else
-            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
-                               d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg);
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
+                               tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 80 && !g_force_v1) {
         const int npan = (nc + 15) >> 4;
         const size_t lds2 = sizeof(double) * 256 * (npan * 5 - (npan * (npan - 1)) / 2);
-        hipLaunchKernelGGL((tsqr2_kernel<5, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau, d_blkw,
-                           rows_per_blk, rpw, Rws_out, nc, g_dbg);
+        hipLaunchKernelGGL((tsqr2_kernel<5, 4, true, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
+                           d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
     else if (nc <= 128) FIGH_TSQR_LAUNCH(2, 32, false);
     else if (nc <= 256) FIGH_TSQR_LAUNCH(4, 16, false);
@@ -849,19 +862,28 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
 }
 
 // reduce `count` stacked nc x nc triangles (in Rs, contiguous) down to one, result in d_R_out
-static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out) {
+// padded: every input triangle occupies 64 rows (nc real + zero rows) so that one 64-row tile is exactly one upper
+// triangular factor and the merge levels can skip the row chunks below the current panel (TRI kernel)
+static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out, bool padded = false) {
     const size_t tri = sizeof(double) * (size_t)nc * nc;
+    const bool use_tri = padded && nc <= 64 && !g_force_v1 && g_force_v2;
+    const long in_rows = padded ? 64 : nc;
     const double *cur = Rs;
     long cnt = count;
     int slot = 2;
     while (cnt > 1) {
         const long fan = 4;
         const long nw_next = (cnt + fan - 1) / fan;
-        double *dst = nw_next == 1 ? d_R_out : static_cast<double *>(workspace(tri * nw_next, slot));
+        const bool last = nw_next == 1;
+        const int out_rows = (use_tri && !last) ? 64 : nc;
+        double *dst = last ? d_R_out
+                           : static_cast<double *>(workspace(sizeof(double) * (size_t)out_rows * nc * nw_next, slot));
         if (!dst) return FIGH_ERR_ALLOC;
         long nw = 0;
         ProfileScope scope("tsqr_reduce");
-        if (int rc = tsqr_level(cur, cnt * nc, nc, nullptr, nc, nullptr, nullptr, 1, nc, nw_next, fan * nc, dst, &nw))
+        const long in_r = (cur == Rs) ? in_rows : (use_tri ? 64 : nc);
+        if (int rc = tsqr_level(cur, cnt * in_r, nc, nullptr, nc, nullptr, nullptr, 1, nc, nw_next, fan * in_r, dst, &nw,
+                                out_rows, use_tri && in_r == 64))
             return rc;
         cur = dst;
         cnt = nw;
@@ -975,20 +997,26 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
         target = cu_count() * 4L;
     }
     const size_t tri = sizeof(double) * (size_t)nc * nc;
+    // level-0 triangles in the zero-padded TRI merge format: measured SLOWER (reduce level 0.208 vs 0.167 ms: 28 %
+    // more tiles outweigh the skipped row chunks), so it stays an A/B option (FIGH_TSQR_TRI)
+    static const bool g_tri = getenv("FIGH_TSQR_TRI") != nullptr;
+    const bool padded = g_tri && nc <= 64 && !g_force_v1 && g_force_v2;
+    const int out_rows = padded ? 64 : nc;
     long nw_est = target + 1;
-    double *Rws = static_cast<double *>(workspace(tri * nw_est, 5));
+    double *Rws = static_cast<double *>(workspace(sizeof(double) * (size_t)out_rows * nc * nw_est, 5));
     if (!Rws) return FIGH_ERR_ALLOC;
     long nw = 0;
     {
         ProfileScope scope(rows >= 65536 ? "tsqr" : "tsqr_small");
-        if (int rc = tsqr_level(d_W, rows, ldw, d_col_idx, n, d_tau, d_blkw, rows_per_blk, nc, target, 64, Rws, &nw))
+        if (int rc = tsqr_level(d_W, rows, ldw, d_col_idx, n, d_tau, d_blkw, rows_per_blk, nc, target, 64, Rws, &nw,
+                                out_rows))
             return rc;
     }
     if (nw == 1) {
         FIGH_HIP(hipMemcpyAsync(d_R_out, Rws, tri, hipMemcpyDeviceToDevice, stream()));
         return FIGH_OK;
     }
-    return tsqr_reduce(Rws, nw, nc, d_R_out);
+    return tsqr_reduce(Rws, nw, nc, d_R_out, padded);
 }
 
 int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out) {
