@@ -137,6 +137,24 @@ def main():
         sec = kern["tsqr"]["avg_ms"] * 1e-3
         roof["tsqr"] = {"bound": "mfma", "achieved": flops_per_sample * N / sec / 1e12, "peak": FP64_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "traffic": None}
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 as the
+    # gfx950 correction + WRITE_SIZE, tools/pmc_summary.py); PMC cannot be read from inside the process
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            pmc = json.load(f)
+        if N == 1_000_000:
+            for key, kname in (("regressor_chain", "regressor_chain_kernel<6, false, true>"),
+                               ("tsqr", "tsqr2_kernel<4, 4, false, false>")):
+                if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
+                    roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
+                    roof[key]["traffic_source"] = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    except Exception:
+        pass
+    if "tsqr" in roof:
+        roof["tsqr"]["pipe"] = "fp64 VALU (v_fma_f64 + DPP/permlane); v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak"
+        roof["tsqr"]["algorithmic_flops_per_sample"] = flops_per_sample
+    if "regressor_chain" in roof:
+        roof["regressor_chain"]["algorithmic_bytes_per_sample"] = bytes_per_sample
     for r in roof.values():
         r["frac"] = r["achieved"] / r["peak"]
     dominant = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if kern else None
