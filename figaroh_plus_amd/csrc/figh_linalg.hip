@@ -292,6 +292,110 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// tsqr_coop_kernel<NCC, NW>: the merge levels.  One workgroup of NW waves factors NW*64 stacked rows (about
+// NW*64/nc triangles) in ONE sweep of column steps instead of NW sequential 64-row tiles: every wave keeps its
+// own 64-row tile in registers, forms its part of x^T B, and the per-wave partial sums are combined through LDS
+// (fixed order: bit-reproducible).  A merge level is latency-bound (few waves on the chip), so its time is the
+// number of dependent column steps: nc per level here, against fan*nc for one wave walking `fan` tiles.
+// The triangle being built starts empty (alpha = 0), so row k is final at step k and is written straight out.
+template <int KK, int NCC, int NW>
+__device__ __forceinline__ void tsqr_coop_step(double (&T)[NCC][16], const int p, const int live, const int nc,
+                                               const int lane_c, const int lane_g, const int wave,
+                                               double (*pw)[NW][16 * NCC], double (*tot)[16 * NCC],
+                                               double *__restrict__ Rg) {
+    const int kabs = 16 * p + KK;
+    const int buf = kabs & 1;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = row_bcast<KK>(T[0][i]);
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        if (cc < live) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                s0 += x[i] * T[cc][i];
+                s1 += x[i + 1] * T[cc][i + 1];
+            }
+            const double dw = allreduce_rowgroups(s0 + s1);
+            if (lane_g == 0) pw[buf][wave][16 * cc + lane_c] = dw;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int l = 16 * lane_g + lane_c;
+        if (l < 16 * live) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += pw[buf][w][l];
+            tot[buf][l] = s;
+        }
+    }
+    __syncthreads();
+    const double sigma = uniform_of(tot[buf][KK]);
+    if (sigma == 0.0) return;  // uniform over the workgroup: every wave read the same total
+    double rs = __builtin_amdgcn_rsq(sigma);
+    rs = rs * fma(-0.5 * sigma * rs, rs, 1.5);
+    rs = rs * fma(-0.5 * sigma * rs, rs, 1.5);
+    double sq = sigma * rs;
+    sq = fma(fma(-sq, sq, sigma), 0.5 * rs, sq);
+    rs = rs * fma(-sq, rs, 2.0);  // 1/s refined against the final s
+    const double beta = -sq;      // alpha = 0: beta = -s, inv = 1/s, tfac = 1
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        if (cc < live) {
+            const double d = tot[buf][16 * cc + lane_c];
+            const bool trail = cc > 0 || lane_c > KK;
+            const double wj = trail ? d * rs : 0.0;
+            const double cj = wj * rs;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[cc][i] -= cj * x[i];
+            const int col = 16 * (p + cc) + lane_c;
+            if (wave == 0 && lane_g == 0 && col < nc && (cc > 0 || lane_c >= KK))
+                Rg[(long)kabs * nc + col] = (cc == 0 && lane_c == KK) ? beta : -wj;
+        }
+    }
+}
+
+template <int NCC, int NW>
+__global__ __launch_bounds__(64 * NW) void tsqr_coop_kernel(const double *__restrict__ Rs, const long rows, const int nc,
+                                                            double *__restrict__ Rout) {
+    __shared__ double pw[2][NW][16 * NCC];
+    __shared__ double tot[2][16 * NCC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane_c = lane & 15, lane_g = lane >> 4;
+    const long r0 = ((long)blockIdx.x * NW + wave) * 64;
+    double *Rg = Rout + (long)blockIdx.x * nc * nc;
+    for (int e = threadIdx.x; e < nc * nc; e += 64 * NW) Rg[e] = 0.0;
+    double T[NCC][16];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long row = r0 + 16 * (i >> 2) + lane_g + 4 * (i & 3);
+            const int col = 16 * cc + lane_c;
+            const bool ok = row < rows && col < nc;
+            const double v = Rs[(ok ? row : 0) * nc + (ok ? col : 0)];
+            T[cc][i] = ok ? v : 0.0;
+        }
+    __syncthreads();  // the zero fill of Rg is ordered before the row stores of wave 0 (same workgroup)
+    const int np = (nc + 15) >> 4;
+    for (int p = 0; p < np; ++p) {
+        const int live = NCC - p;
+#define FIGH_CSTEP(KK) \
+    if (16 * p + KK < nc) tsqr_coop_step<KK, NCC, NW>(T, p, live, nc, lane_c, lane_g, wave, pw, tot, Rg);
+        FIGH_CSTEP(0) FIGH_CSTEP(1) FIGH_CSTEP(2) FIGH_CSTEP(3) FIGH_CSTEP(4) FIGH_CSTEP(5) FIGH_CSTEP(6) FIGH_CSTEP(7)
+        FIGH_CSTEP(8) FIGH_CSTEP(9) FIGH_CSTEP(10) FIGH_CSTEP(11) FIGH_CSTEP(12) FIGH_CSTEP(13) FIGH_CSTEP(14)
+        FIGH_CSTEP(15)
+#undef FIGH_CSTEP
+#pragma unroll
+        for (int cc = 0; cc + 1 < NCC; ++cc)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[cc][i] = T[cc + 1][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // tsqr3_kernel<NCC>: blocked Householder (compact WY) on the same register tile.  A 16-column panel is factored
 // with the DPP / permlane step above restricted to the panel itself; its 16 reflectors are then applied to every
 // trailing 16-column chunk as three v_mfma_f64_16x16x4_f64 contractions
@@ -864,7 +968,37 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
 // reduce `count` stacked nc x nc triangles (in Rs, contiguous) down to one, result in d_R_out
 // padded: every input triangle occupies 64 rows (nc real + zero rows) so that one 64-row tile is exactly one upper
 // triangular factor and the merge levels can skip the row chunks below the current panel (TRI kernel)
+static int tsqr_reduce_tree(const double *Rs, long count, int nc, double *d_R_out, bool padded);
+
+// reduce `count` stacked compact nc x nc triangles (contiguous in Rs) to one in d_R_out
 static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out, bool padded = false) {
+    static const bool g_tree = getenv("FIGH_TSQR_TREE") != nullptr;  // A/B: single-wave 4:1 tree levels
+    if (padded || nc > 64 || g_force_v1 || g_tree) return tsqr_reduce_tree(Rs, count, nc, d_R_out, padded);
+    const size_t tri = sizeof(double) * (size_t)nc * nc;
+    const double *cur = Rs;
+    long cnt = count;
+    int slot = 2;
+    while (cnt > 1) {
+        const long rows = cnt * nc;
+        const int nwv = rows > 256 ? 8 : 4;
+        const long nb = (rows + 64L * nwv - 1) / (64L * nwv);
+        double *dst = nb == 1 ? d_R_out : static_cast<double *>(workspace(tri * nb, slot));
+        if (!dst) return FIGH_ERR_ALLOC;
+        ProfileScope scope("tsqr_reduce");
+        if (nwv == 8)
+            hipLaunchKernelGGL((tsqr_coop_kernel<4, 8>), dim3((unsigned)nb), dim3(512), 0, stream(), cur, rows, nc, dst);
+        else
+            hipLaunchKernelGGL((tsqr_coop_kernel<4, 4>), dim3((unsigned)nb), dim3(256), 0, stream(), cur, rows, nc, dst);
+        FIGH_HIP(hipGetLastError());
+        cur = dst;
+        cnt = nb;
+        slot = slot == 2 ? 3 : 2;
+    }
+    if (cur != d_R_out) FIGH_HIP(hipMemcpyAsync(d_R_out, cur, tri, hipMemcpyDeviceToDevice, stream()));
+    return FIGH_OK;
+}
+
+static int tsqr_reduce_tree(const double *Rs, long count, int nc, double *d_R_out, bool padded) {
     const size_t tri = sizeof(double) * (size_t)nc * nc;
     const bool use_tri = padded && nc <= 64 && !g_force_v1 && g_force_v2;
     const long in_rows = padded ? 64 : nc;
