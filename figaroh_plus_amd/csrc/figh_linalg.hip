@@ -323,8 +323,7 @@ __device__ __forceinline__ void tsqr_coop_step(double (&T)[NCC][16], const int p
     }
     __syncthreads();
     if (wave == 0) {
-        const int l = 16 * lane_g + lane_c;
-        if (l < 16 * live) {
+        for (int l = 16 * lane_g + lane_c; l < 16 * live; l += 64) {
             double s = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += pw[buf][w][l];
@@ -973,20 +972,22 @@ static int tsqr_reduce_tree(const double *Rs, long count, int nc, double *d_R_ou
 // reduce `count` stacked compact nc x nc triangles (contiguous in Rs) to one in d_R_out
 static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out, bool padded = false) {
     static const bool g_tree = getenv("FIGH_TSQR_TREE") != nullptr;  // A/B: single-wave 4:1 tree levels
-    if (padded || nc > 64 || g_force_v1 || g_tree) return tsqr_reduce_tree(Rs, count, nc, d_R_out, padded);
+    if (padded || nc > 80 || g_force_v1 || g_tree) return tsqr_reduce_tree(Rs, count, nc, d_R_out, padded);
     const size_t tri = sizeof(double) * (size_t)nc * nc;
     const double *cur = Rs;
     long cnt = count;
     int slot = 2;
     while (cnt > 1) {
         const long rows = cnt * nc;
-        const int nwv = rows > 256 ? 8 : 4;
+        const int nwv = (rows > 256 && nc <= 64) ? 8 : 4;  // 5 column chunks per lane need > 256 registers: 4 waves
         const long nb = (rows + 64L * nwv - 1) / (64L * nwv);
         double *dst = nb == 1 ? d_R_out : static_cast<double *>(workspace(tri * nb, slot));
         if (!dst) return FIGH_ERR_ALLOC;
         ProfileScope scope("tsqr_reduce");
         if (nwv == 8)
             hipLaunchKernelGGL((tsqr_coop_kernel<4, 8>), dim3((unsigned)nb), dim3(512), 0, stream(), cur, rows, nc, dst);
+        else if (nc > 64)
+            hipLaunchKernelGGL((tsqr_coop_kernel<5, 4>), dim3((unsigned)nb), dim3(256), 0, stream(), cur, rows, nc, dst);
         else
             hipLaunchKernelGGL((tsqr_coop_kernel<4, 4>), dim3((unsigned)nb), dim3(256), 0, stream(), cur, rows, nc, dst);
         FIGH_HIP(hipGetLastError());
@@ -1129,6 +1130,11 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
         target = cu_count() * per_cu;
     } else if (nc <= 64) {
         target = cu_count() * 4L;
+    }
+    {   // a leaf must be much taller than wide, or the "reduction" produces more triangle rows than it consumed
+        long cap = rows / (8L * nc);
+        if (cap < 1) cap = 1;
+        if (target > cap) target = cap;
     }
     const size_t tri = sizeof(double) * (size_t)nc * nc;
     // level-0 triangles in the zero-padded TRI merge format: measured SLOWER (reduce level 0.208 vs 0.167 ms: 28 %

@@ -123,5 +123,19 @@ def exchange_from_env(prefer="rccl"):
             dist.broadcast_object_list(obj, src=0)
             return obj[0]
 
-        return RcclExchange(world, rank, bcast), {"collective": "rccl"}
+        # RCCL needs one distinct GPU per rank; if the communicator cannot be built on ANY rank (e.g. two ranks
+        # sharing a device in a test), every rank takes the host-staged exchange instead -- decided collectively
+        # so that no rank is left waiting in a collective, and reported in the bench line.
+        ex, err = None, ""
+        try:
+            ex = RcclExchange(world, rank, bcast)
+        except Exception as e:  # noqa: BLE001
+            err = str(e)
+        flags = [None] * world
+        dist.all_gather_object(flags, ex is not None)
+        if all(flags):
+            return ex, {"collective": "rccl"}
+        if ex is not None:
+            ex.close()
+        return TorchExchange(), {"collective": "torch.distributed/gloo host-staged (rccl unavailable: %s)" % err[:80]}
     return TorchExchange(), {"collective": "torch.distributed/" + dist.get_backend()}

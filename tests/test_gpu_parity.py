@@ -309,3 +309,26 @@ def test_full_size_structural_invariants(lib, cfg, N, oracle_lib):
     for k, r in enumerate(rows):  # row gather through the ABI: d2h of one row each
         _lib.check(_lib.load().figh_memcpy_d2h(host_rows[k].ctypes.data, W.buf.ptr + int(r) * W.ld * 8, W.cols * 8))
     assert np.abs(host_rows - Wsel).max() <= 1e-12 * np.abs(Wsel).max()
+
+
+# ------------------------------------------------------------------------------------------------ RCCL plumbing
+def test_rccl_single_rank_roundtrip(lib):
+    """The RCCL entry points on the one GPU a test box has: communicator of size 1, all-gather and all-reduce
+    must return the input (validates the lazy dlopen, the symbol signatures and the stream the calls run on)."""
+    import ctypes as C
+    buf = C.create_string_buffer(128)
+    l = lib.load()
+    lib.check(l.figh_comm_unique_id(buf))
+    lib.check(l.figh_comm_init(1, 0, buf))
+    try:
+        x = np.arange(50 * 50, dtype=np.float64)
+        d_x = lib.DeviceArray.from_host(x)
+        d_all = lib.DeviceArray((x.size,))
+        lib.check(l.figh_comm_allgather(d_x.ptr, d_all.ptr, x.size))
+        assert np.array_equal(d_all.to_host(), x)
+        lib.check(l.figh_comm_allreduce_sum(d_x.ptr, x.size))
+        assert np.array_equal(d_x.to_host(), x)
+        with pytest.raises(lib.FighError):
+            lib.check(l.figh_comm_init(1, 0, buf))  # already initialised
+    finally:
+        lib.check(l.figh_comm_destroy())
