@@ -34,8 +34,21 @@ class Exchange:
         return d_R, 1
 
 
+class _View:
+    """A window into a DeviceArray (no ownership): what the C-ABI wrappers need is ``.ptr``."""
+
+    def __init__(self, base, byte_offset):
+        self.ptr = base.ptr + int(byte_offset)
+
+
 class IdentificationPipeline:
-    def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None):
+    def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
+                 chunk_samples=None):
+        """``chunk_samples``: when the stacked regressor of all N samples does not fit HBM (human model at 1e7
+        samples: 269 GB) the samples are processed in chunks of this size -- pass 1 accumulates diag(W^T W), pass 2
+        rebuilds each chunk's W (recomputing is far cheaper than storing), factors it and stacks the triangles,
+        which ``figh_tsqr_merge`` reduces.  Results are those of the one-shot pass (R is row-order independent)."""
+        self.chunk_samples = chunk_samples
         self.robot, self.param, self.coupling = robot, param, coupling
         self.tol_e, self.tol_qr = tol_e, tol_qr
         self.params_std = params_std if params_std is not None else robot.get_standard_parameters(param)
@@ -57,8 +70,46 @@ class IdentificationPipeline:
             np.ascontiguousarray(tau, dtype=np.float64).reshape(-1))
         self.W = None
 
+    def _chunks(self):
+        c = self.chunk_samples
+        return [(lo, min(lo + c, self.N)) for lo in range(0, self.N, c)]
+
+    def _chunked(self):
+        return bool(self.chunk_samples) and self.N > self.chunk_samples
+
+    def _build_chunk(self, lo, hi, W, d_colsq):
+        from .tools.regressor import regressor_flags
+        mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+        m = self.robot.model
+        _lib.regressor_build(self.robot.device_model(), mode, flags, ft_mask, hi - lo, _View(self.d_q, lo * m.nq * 8),
+                             _View(self.d_v, lo * m.nv * 8), _View(self.d_a, lo * m.nv * 8), W.buf, W.ld, d_colsq)
+
+    def _tau_chunk(self, lo, hi, rps, d_out, scatter=False):
+        """gather (or scatter back) the rows j*N + [lo, hi) of tau <-> the chunk's joint-major vector"""
+        lib, nch = _lib.load(), hi - lo
+        for j in range(rps):
+            full, part = self.d_tau.ptr + (j * self.N + lo) * 8, d_out.ptr + j * nch * 8
+            _lib.check(lib.figh_memcpy_d2d(full, part, nch * 8) if scatter else lib.figh_memcpy_d2d(part, full, nch * 8))
+
     def set_tau_from_parameters(self, phi, noise_std=0.0, seed=0):
         """Synthetic measurement tau = W phi + noise, built on the device (bench / tests)."""
+        if self._chunked():
+            from .tools.regressor import regressor_flags
+            mode, flags, _ = regressor_flags(self.param, self.coupling)
+            rps, ncols = self.robot.device_model().shape(mode, flags)
+            d_phi = _lib.DeviceArray.from_host(np.ascontiguousarray(phi, dtype=np.float64))
+            self.d_tau = _lib.DeviceArray((rps * self.N,), np.float64)
+            Wc = GpuMatrix.empty(rps * self.chunk_samples, ncols)
+            d_t = _lib.DeviceArray((rps * self.chunk_samples,), np.float64)
+            for lo, hi in self._chunks():
+                self._build_chunk(lo, hi, Wc, None)
+                _lib.matvec(Wc.buf, rps * (hi - lo), Wc.ld, None, ncols, d_phi, d_t)
+                self._tau_chunk(lo, hi, rps, d_t, scatter=True)
+            if noise_std > 0.0:
+                tau = self.d_tau.to_host()
+                tau += np.random.default_rng(seed).standard_normal(tau.shape[0]) * noise_std
+                self.d_tau = _lib.DeviceArray.from_host(tau)
+            return self.d_tau
         W, _ = build_regressor_device(self.robot, self.d_q, self.d_v, self.d_a, self.N, self.param, self.coupling)
         d_phi = _lib.DeviceArray.from_host(np.ascontiguousarray(phi, dtype=np.float64))
         d_tau = _lib.DeviceArray((W.rows,), np.float64)
@@ -72,7 +123,57 @@ class IdentificationPipeline:
         return d_tau
 
     # ------------------------------------------------------------------ one pass of the hot path
+    def _run_chunked(self, strings):
+        from .tools.regressor import regressor_flags
+        ex, lib = self.exchange, _lib.load()
+        mode, flags, _ = regressor_flags(self.param, self.coupling)
+        rps, ncols = self.robot.device_model().shape(mode, flags)
+        chunks = self._chunks()
+        if self.W is None or self.W.rows != rps * self.chunk_samples:
+            self.W = GpuMatrix.empty(rps * self.chunk_samples, ncols)
+            cap = ncols + 1
+            self._d_colsq = _lib.DeviceArray((ncols,), np.float64)
+            self._d_idx = _lib.DeviceArray((cap,), np.int32)
+            self._d_Rm = _lib.DeviceArray((cap * cap,), np.float64)
+            self._d_Rp = _lib.DeviceArray((cap * cap,), np.float64)
+            self._d_R2 = _lib.DeviceArray((cap * cap,), np.float64)
+            self._d_stack = _lib.DeviceArray((len(chunks) * cap * cap,), np.float64)
+            self._d_tauc = _lib.DeviceArray((rps * self.chunk_samples,), np.float64)
+        W = self.W
+        # pass 1: column norms (W chunk written and discarded)
+        col_local = np.zeros(ncols)
+        for lo, hi in chunks:
+            self._build_chunk(lo, hi, W, self._d_colsq)
+            col_local += self._d_colsq.to_host()
+        d_tot = _lib.DeviceArray.from_host(col_local)
+        col_norm = ex.sum_columns(d_tot, ncols)
+        idx_e = [i for i in range(ncols) if col_norm[i] < self.tol_e]
+        kept = [i for i in range(ncols) if not col_norm[i] < self.tol_e]
+        params_r = [self.names[i] for i in kept]
+        n = len(kept)
+        with_tau = self.d_tau is not None
+        nc = n + (1 if with_tau else 0)
+        kept_i32 = np.asarray(kept, dtype=np.int32)
+        _lib.check(lib.figh_memcpy_h2d(self._d_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
+        # pass 2: rebuild each chunk, factor it, stack the triangles
+        for k, (lo, hi) in enumerate(chunks):
+            self._build_chunk(lo, hi, W, None)
+            d_tc = None
+            if with_tau:
+                self._tau_chunk(lo, hi, rps, self._d_tauc)
+                d_tc = self._d_tauc
+            _lib.tsqr(W.buf, rps * (hi - lo), W.ld, self._d_idx, n, d_tc, None, _View(self._d_stack, k * nc * nc * 8))
+        d_R = self._d_Rm
+        _lib.tsqr_merge(self._d_stack, len(chunks), nc, d_R)
+        d_stack, count = ex.stack_triangles(d_R, nc)
+        if count > 1:
+            d_R = _lib.DeviceArray((nc * nc,), np.float64)
+            _lib.tsqr_merge(d_stack, count, nc, d_R)
+        return self._tail(d_R, n, nc, params_r, idx_e, col_norm, with_tau, rps * self.N * ex.world_size, strings)
+
     def run(self, strings=True):
+        if self._chunked():
+            return self._run_chunked(strings)
         ex = self.exchange
         # K1 (+ fused column norms)
         from .tools.regressor import regressor_flags
@@ -106,6 +207,10 @@ class IdentificationPipeline:
         if count > 1:
             _lib.tsqr_merge(d_stack, count, nc, self._d_Rm)
             d_R = self._d_Rm
+        return self._tail(d_R, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+
+    def _tail(self, d_R, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
+        lib, d_idx = _lib.load(), self._d_idx
         R = np.empty((nc, nc))
         _lib.check(lib.figh_memcpy_d2h(R.ctypes.data, d_R.ptr, R.nbytes))
         R = np.triu(R)
@@ -124,7 +229,7 @@ class IdentificationPipeline:
         beta = np.around(R1_inv @ R2, 6)
         out = {
             "idx_e": idx_e, "params_r": params_r, "idx_base": idx_base, "beta": beta,
-            "col_norm": col_norm, "absdiagR": np.abs(np.diag(R)[:n]), "rows": W.rows * ex.world_size,
+            "col_norm": col_norm, "absdiagR": np.abs(np.diag(R)[:n]), "rows": total_rows,
         }
         if strings:
             out["params_base"] = qrd._expressions([params_r[i] for i in idx_base],
