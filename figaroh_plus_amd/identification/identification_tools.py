@@ -105,11 +105,26 @@ def relative_stdev(W_b, phi_b, tau):
 
 
 def block_residual_sqnorms(tau_meas, tau_est, nblocks):
-    """Per-joint squared residual norms ||tau_j - tau_est_j||^2 on the device."""
+    """Per-joint squared residual norms ||tau_j - tau_est_j||^2 on the device.  ``nblocks``: a number of
+    equal blocks, or the list of block lengths (joints keep different numbers of rows after the zero-velocity
+    rejection, examples/staubli_TX40/identification.py:207-233)."""
     d_a, d_b = vector_to_device(tau_meas), vector_to_device(tau_est)
-    out = _lib.DeviceArray((nblocks,), np.float64)
-    _lib.block_sqnorm(d_a, d_b, d_a.size, nblocks, out)
-    return out.to_host()
+    if np.isscalar(nblocks):
+        out = _lib.DeviceArray((int(nblocks),), np.float64)
+        _lib.block_sqnorm(d_a, d_b, d_a.size, int(nblocks), out)
+        return out.to_host()
+    res, off = [], 0
+    one = _lib.DeviceArray((1,), np.float64)
+
+    class _At:
+        def __init__(self, base, k):
+            self.ptr = base.ptr + 8 * k
+
+    for n_i in nblocks:
+        _lib.block_sqnorm(_At(d_a, off), _At(d_b, off), int(n_i), 1, one)
+        res.append(float(one.to_host()[0]))
+        off += int(n_i)
+    return np.array(res)
 
 
 def weigthed_least_squares(robot, phi_b, W_b, tau_meas, tau_est, param):
@@ -133,18 +148,95 @@ def weigthed_least_squares(robot, phi_b, W_b, tau_meas, tau_est, param):
 
 
 def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks):
-    """Script WLS of examples/staubli_TX40/identification.py:305-346 for ``nblocks`` equal joint blocks:
-    sigma_j^2 = ||tau_j - W_j phi_b||^2 / n_j, phi = (W^T S^-1 W)^-1 W^T S^-1 tau (6 decimals),
-    C_X = (W^T S^-1 W)^-1, std% = 100 sqrt(diag C_X) / |phi| (2 decimals).  Returns (phi, std%)."""
+    """Script WLS of examples/staubli_TX40/identification.py:305-346.  ``nblocks``: number of equal joint blocks or
+    the list of block lengths.  sigma_j^2 = ||tau_j - W_j phi_b||^2 / n_j, phi = (W^T S^-1 W)^-1 W^T S^-1 tau
+    (6 decimals), C_X = (W^T S^-1 W)^-1, std% = 100 sqrt(diag C_X) / |phi| (2 decimals).  Returns (phi, std%)."""
     Wd, _ = to_device(W_b)
     phi_b = np.ascontiguousarray(phi_b, dtype=np.float64)
     d_est = _lib.DeviceArray((Wd.rows,), np.float64)
     _lib.matvec(Wd.buf, Wd.rows, Wd.ld, None, Wd.cols, vector_to_device(phi_b), d_est)
     sq = block_residual_sqnorms(tau, d_est, nblocks)
-    sig2 = sq / (Wd.rows // nblocks)
-    R, z, _ = _triangle_with_tau(Wd, tau, block_weight=1.0 / np.sqrt(sig2))
+    if np.isscalar(nblocks):
+        sig2 = sq / (Wd.rows // int(nblocks))
+        weights = 1.0 / np.sqrt(sig2)
+    else:
+        counts = np.asarray(nblocks, dtype=np.int64)
+        weights = np.repeat(1.0 / np.sqrt(sq / counts), counts)  # one weight per row
+    R, z, _ = _triangle_with_tau(Wd, tau, block_weight=weights)
     phi = np.around(np.linalg.solve(R, z), 6)
     R_inv = np.linalg.inv(R)
     C_X = R_inv @ R_inv.T
     std = np.round(100 * np.sqrt(np.diag(C_X)) / np.abs(phi), 2)
     return phi, std
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Pre-processing on either side of the hot path (SURVEY.md section 8f-1, "next" row).  Host NumPy / SciPy for now:
+# O(N nq) work on the trajectories, same statements and quirks as the reference.
+def joint_difference(model, q0, q1):
+    """``pin.difference(model, q0, q1)`` for the joint types of the URDF loader (tangent-space difference)."""
+    out = np.zeros(model.nv)
+    for j in model.joints[1:]:
+        if j.jtype in (0, 1):
+            out[j.idx_v] = q1[j.idx_q] - q0[j.idx_q]
+        elif j.jtype == 2:  # (cos, sin): angle of R0^T R1
+            c0, s0, c1, s1 = q0[j.idx_q], q0[j.idx_q + 1], q1[j.idx_q], q1[j.idx_q + 1]
+            out[j.idx_v] = np.arctan2(s1 * c0 - c1 * s0, c1 * c0 + s1 * s0)
+        else:
+            raise NotImplementedError("joint_difference: free-flyer joints (SE(3) log) are not implemented yet")
+    return out
+
+
+def calculate_first_second_order_differentiation(model, q, param, dt=None):
+    """(q, dq, ddq) by finite differences -- identification_tools.py:334-387, including its conventions: forward
+    difference for dq, ``np.gradient`` of dq for ddq on joints ``range(model.nq - 1)`` only (the last joint's
+    acceleration stays 0 for fixed-base robots), two samples dropped from q and one from dq / ddq."""
+    q = np.asarray(q, dtype=np.float64)
+    ncol = q.shape[1] if param["is_joint_torques"] else q.shape[1] - 1
+    if param["is_external_wrench"]:
+        ncol = q.shape[1] - 1
+    dq = np.zeros([q.shape[0] - 1, ncol])
+    ddq = np.zeros([q.shape[0] - 1, ncol])
+    only_simple = all(j.jtype in (0, 1) for j in model.joints[1:])
+    if only_simple and model.nq == model.nv == ncol:
+        step = np.diff(q, axis=0)
+        dq[:, :] = step / (param["ts"] if dt is None else np.asarray(dt)[:len(step), None])
+    else:
+        for ii in range(q.shape[0] - 1):
+            dq[ii, :] = joint_difference(model, q[ii, :], q[ii + 1, :]) / (param["ts"] if dt is None else dt[ii])
+    h = param["ts"] if dt is None else dt
+    for jj in range(model.nq - 1):
+        ddq[:, jj] = np.gradient(dq[:, jj], edge_order=1) / h
+    return q[:-2], dq[:-1], ddq[:-1]
+
+
+def low_pass_filter_data(data, param, nbutter=5):
+    """Zero-phase Butterworth low-pass + border trimming -- identification_tools.py:390-424."""
+    from scipy import signal
+
+    cutoff = param["ts"] * param["cut_off_frequency_butterworth"] / 2
+    b, a = signal.butter(nbutter, cutoff, "low")
+    padlen = 3 * (max(len(b), len(a)) - 1)
+    data = signal.filtfilt(b, a, data, axis=0, padtype="odd", padlen=padlen)
+    nbord = 5 * nbutter
+    return data[nbord:data.shape[0] - nbord]
+
+
+def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
+    """Per-joint decimation of tau and of every column of W with ``scipy.signal.decimate(zero_phase=True)``
+    (examples/staubli_TX40/identification.py:186-204, examples/tiago/identification.py:142-187).
+    Returns (list of W blocks, list of tau blocks).  Host SciPy for now ("next" row)."""
+    from scipy import signal
+
+    W = np.asarray(W)
+    nj = tau.shape[0] // nblocks
+    W_list, tau_list = [], []
+    for i in range(nblocks):
+        t = tau[i * nj:(i + 1) * nj]
+        blk = W[i * nj:i * nj + nj]
+        for _ in range(stages):
+            t = signal.decimate(t, q=q, zero_phase=True)
+            blk = signal.decimate(blk, q=q, zero_phase=True, axis=0)
+        W_list.append(np.ascontiguousarray(blk))
+        tau_list.append(t)
+    return W_list, tau_list

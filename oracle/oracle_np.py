@@ -19,7 +19,9 @@ What is restated, and what pins it
   ``regressor.py`` / ``qrdecomposition.py`` / ``robot.py`` from /root/reference
   on top of this function): the 60 base-parameter expressions of
   ``examples/staubli_TX40/results/TX40_bp_5.csv``, the TIAGo joint numbering and
-  the human body list.
+  the human body list, and (iii) the NUMBERS of that CSV (phi_OLS, sigma%, phi_WLS),
+  reproduced from the reference's committed TX40 measurements to <= 3.8e-4
+  (``oracle/gen_golden_tx40_real.py``, ``tests/test_oracle.py::test_tx40_real_data_known_answers``).
 * everything else (row/column layout, elimination, QR bookkeeping, strings,
   LS/WLS/sigma) restates plain NumPy code of the reference and is pinned against
   outputs of the reference itself (``tests/golden/*.npz``).

@@ -357,3 +357,42 @@ def test_chunked_pipeline_equals_one_shot(lib, golden):
     tau = pipe2.set_tau_from_parameters(phi).to_host()
     W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
     assert np.abs(tau - W @ phi).max() <= 1e-11 * max(1.0, np.abs(W @ phi).max())
+
+
+def test_tx40_real_data_known_answers_hip(lib):
+    """Same known-answer replay with the HIP path: K1 on the 44 958 real samples, then (after the host-side
+    decimation, a 'next' row) elimination, double_QR, sigma, OLS and WLS through the kernels; compared with the
+    reference's committed TX40_bp_5.csv and with the reference-produced fixture."""
+    from tx40_real_common import decimate_and_filter, load_fixture, trajectories, tx40
+    from figaroh_plus_amd.identification.identification_tools import (least_squares, relative_stdev,
+                                                                       weighted_least_squares_blocks)
+    from figaroh_plus_amd.tools.qrdecomposition import double_QR
+    from figaroh_plus_amd.tools.regressor import add_coupling_TX40, build_regressor_basic, eliminate_non_dynaffect
+    z, meta = load_fixture()
+    g, robot, param, params_std = tx40()
+    q, dq, ddq, tau = trajectories(z, robot, param)
+    m = robot.model
+    W = build_regressor_basic(robot, q, dq, ddq, param)
+    W = add_coupling_TX40(W, m, robot.data, len(q), m.nq, m.nv, m.njoints, q, dq, ddq)
+    chk = np.array([W.sum(), np.abs(W).sum(), (W * W).sum()])
+    assert np.abs(chk - z["W_checksum"]).max() <= 1e-11 * np.abs(z["W_checksum"]).max()
+    W_, tau_, counts = decimate_and_filter(W, tau, param)
+    assert counts == list(z["counts"])
+    assert np.abs(W_[::97] - z["W_dec_rows"]).max() <= 1e-10 * np.abs(W_).max()
+    W_e, params_r = eliminate_non_dynaffect(W_, params_std, 0.001)
+    assert params_r == meta["params_r"]
+    W_b, base_parameters, params_base, phi_b = double_QR(tau_, W_e, params_r)
+    assert params_base == meta["csv_expressions"]
+    csvv = z["csv"]
+    assert np.abs(phi_b - z["phi_b"]).max() <= 1.5e-6
+    assert np.abs(phi_b - csvv[:, 0]).max() <= 4e-4
+    std = relative_stdev(W_b, phi_b, tau_)
+    assert np.abs(std - z["std_ols"]).max() <= 0.011 + 1e-4 * np.abs(z["std_ols"]).max()
+    assert (np.abs(std - csvv[:, 1]) / csvv[:, 1]).max() <= 0.012
+    phi_ols = np.around(least_squares(W_b, tau_), 6)
+    assert np.abs(phi_ols - z["phi_ols"]).max() <= 1.5e-6
+    phi_w, std_w = weighted_least_squares_blocks(W_b, tau_, phi_b, counts)
+    assert np.abs(phi_w - z["phi_wls"]).max() <= 1.5e-6
+    assert np.abs(phi_w - csvv[:, 2]).max() <= 4e-4
+    ok = z["std_wls"] < 1e3
+    assert (np.abs(std_w - z["std_wls"])[ok] / z["std_wls"][ok]).max() <= 2e-3

@@ -107,3 +107,38 @@ def test_model_anchors(golden):
     if golden.name == "cfg2_ur10":
         assert golden.meta["params_base"][0] == ("Izz1 + 1.0*Iyy2 + 1.0*Iyy3 + 0.375401*m3 + 1.0*Iyy4 + 0.3483*mz4"
                                                 " + 0.732399*m4 + 0.732399*m5 + 0.732399*m6")
+
+
+def test_tx40_real_data_known_answers(oracle_lib):
+    """The reference's committed measurements -> its committed results (TX40_bp_5.csv) through the oracle.
+    Pins the restated Pinocchio regressor on real trajectories: same 60 expressions, phi within the CSV's
+    reproduction noise (scipy filter version drift, <= 4e-4), sigma% within 1.2 %."""
+    from tx40_real_common import decimate_and_filter, load_fixture, trajectories, tx40
+    z, meta = load_fixture()
+    g, robot, param, params_std = tx40()
+    q, dq, ddq, tau = trajectories(z, robot, param)
+    sel = z["row_sel"]
+    assert np.array_equal(q[sel], z["q_rows"]) and np.array_equal(dq[sel], z["dq_rows"])
+    assert np.array_equal(ddq[sel], z["ddq_rows"])
+    assert np.allclose([q.sum(), dq.sum(), ddq.sum(), np.abs(ddq).sum()], z["qsum"], rtol=1e-13, atol=0)
+    assert not ddq[:, 5].any()  # reference quirk: range(model.nq - 1) leaves the last joint's acceleration at 0
+    om = oracle_lib.OracleModel(g.flat())
+    W = om.build_regressor_basic(q, dq, ddq, 0, 15)
+    chk = np.array([W.sum(), np.abs(W).sum(), (W * W).sum()])
+    assert np.abs(chk - z["W_checksum"]).max() <= 1e-11 * np.abs(z["W_checksum"]).max()
+    W_, tau_, counts = decimate_and_filter(W, tau, param)
+    assert counts == list(z["counts"])
+    assert np.abs(tau_ - z["tau_dec"]).max() <= 1e-12 * np.abs(tau_).max()
+    assert np.abs(W_[::97] - z["W_dec_rows"]).max() <= 1e-10 * np.abs(W_).max()
+    idx_e, params_r = oracle_np.get_index_eliminate(W_, list(params_std.keys()), 0.001)
+    assert params_r == meta["params_r"]
+    res = oracle_np.base_parameters(np.delete(W_, idx_e, 1), params_r, tau=tau_)
+    assert res["params_base"] == meta["csv_expressions"]          # the 60 committed expressions, in order
+    assert np.abs(res["phi_b"] - z["phi_b"]).max() <= 2e-6
+    csvv = z["csv"]
+    assert np.abs(res["phi_b"] - csvv[:, 0]).max() <= 4e-4         # committed phi_OLS
+    std = oracle_np.relative_stdev(res["W_b"], res["phi_b"], tau_)
+    assert (np.abs(std - csvv[:, 1]) / csvv[:, 1]).max() <= 0.012  # committed sigma%
+    phi_w, std_w = oracle_np.wls_script(res["W_b"], tau_, res["phi_b"], counts)
+    assert np.abs(phi_w - z["phi_wls"]).max() <= 2e-6
+    assert np.abs(phi_w - csvv[:, 2]).max() <= 4e-4                # committed phi_WLS
