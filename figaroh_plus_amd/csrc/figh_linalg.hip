@@ -292,6 +292,163 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// tsqr_wide_kernel<CPW>: 80 < n <= 384 columns (TIAGo 241, TALOS 331, human 191).  The tile is too wide for one
+// wave, so a workgroup of 8 waves splits the COLUMNS of the same 64 rows: wave w owns the 16-column chunks
+// w, w+8, w+16 (CPW per wave) in the C-layout registers of tsqr2.  Per column step the owner of the pivot chunk
+// broadcasts the pivot column (64 doubles) and alpha through LDS (ping-pong buffers: one barrier per step), every
+// wave forms sigma = x^T x and its own dot products, and updates its own chunks and its part of row k of the
+// triangle, which lives in global memory (one private nc x nc triangle per workgroup; row k+1 is prefetched while
+// step k runs).  Tiles are dealt round-robin to the workgroups; the same kernel reduces the stacked triangles.
+template <int KK, int CPW>
+__device__ __forceinline__ void tsqr_wide_step(double (&T)[CPW][16], const int p, const int nchunks, const int nc,
+                                               const int lane_c, const int lane_g, const int wave,
+                                               double (*xl)[80], double *__restrict__ Rg, double (&Rk)[CPW],
+                                               double (&Rn)[CPW]) {
+    constexpr int NW = 8;
+    const int k = 16 * p + KK;
+    const int buf = k & 1;
+    const int wo = p & (NW - 1), so = p >> 3;  // owner wave and its slot of the pivot chunk
+    if (wave == wo) {
+        double xo[16];
+#pragma unroll
+        for (int s = 0; s < CPW; ++s)
+            if (s == so) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) xo[i] = row_bcast<KK>(T[s][i]);
+                const double a0 = row_bcast<KK>(Rk[s]);
+                if (lane_c == 0 && lane_g == 0) xl[buf][64] = a0;
+            }
+        if (lane_c == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xl[buf][16 * (i >> 2) + lane_g + 4 * (i & 3)] = xo[i];
+        }
+    }
+    __syncthreads();
+    double x[16];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        x[i] = xl[buf][16 * (i >> 2) + lane_g + 4 * (i & 3)];
+        ss = fma(x[i], x[i], ss);
+    }
+    const double alpha = xl[buf][64];
+    const double sigma = allreduce_rowgroups(ss);
+    // prefetch row k+1 of the triangle (not touched by this step)
+#pragma unroll
+    for (int s = 0; s < CPW; ++s) {
+        const int col = 16 * (wave + NW * s) + lane_c;
+        Rn[s] = (k + 1 < nc && col < nc && wave + NW * s < nchunks) ? Rg[(long)(k + 1) * nc + col] : 0.0;
+    }
+    if (uniform_of(sigma) != 0.0) {
+        const double q2 = fma(alpha, alpha, sigma);
+        double rs = __builtin_amdgcn_rsq(q2);
+        rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
+        rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
+        double sq = q2 * rs;
+        sq = fma(fma(-sq, sq, q2), 0.5 * rs, sq);
+        const double dsum = fabs(alpha) + sq;
+        double ri = __builtin_amdgcn_rcp(dsum);
+        ri = ri * fma(-dsum, ri, 2.0);
+        ri = ri * fma(-dsum, ri, 2.0);
+        const double beta = -copysign(sq, alpha);
+        const double inv = copysign(ri, alpha);
+        const double tfac = dsum * rs;
+#pragma unroll
+        for (int s = 0; s < CPW; ++s) {
+            const int chunk = wave + NW * s;
+            if (chunk >= p && chunk < nchunks) {
+                const int col = 16 * chunk + lane_c;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    s0 += x[i] * T[s][i];
+                    s1 += x[i + 1] * T[s][i + 1];
+                }
+                const double d = allreduce_rowgroups(s0 + s1);
+                const bool trail = col > k;
+                const double wj = trail ? (Rk[s] + d * inv) * tfac : 0.0;
+                const double cj = wj * inv;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) T[s][i] -= cj * x[i];
+                const double rnew = (col == k) ? beta : Rk[s] - wj;
+                if (lane_g == 0 && col >= k && col < nc) Rg[(long)k * nc + col] = rnew;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < CPW; ++s) Rk[s] = Rn[s];
+}
+
+template <int CPW>
+__global__ __launch_bounds__(512) void tsqr_wide_kernel(const double *__restrict__ W, const long rows, const long ldw,
+                                                        const int *__restrict__ col_idx, const int n,
+                                                        const double *__restrict__ tau, const double *__restrict__ blkw,
+                                                        const long rows_per_blk, double *__restrict__ Rws, const int nc) {
+    constexpr int NW = 8;
+    __shared__ double xl[2][80];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane_c = lane & 15, lane_g = lane >> 4;
+    const int nchunks = (nc + 15) >> 4;
+    double *Rg = Rws + (long)blockIdx.x * nc * nc;
+    for (long e = threadIdx.x; e < (long)nc * nc; e += 512) Rg[e] = 0.0;
+    __syncthreads();
+
+    const double *src[CPW];
+    long stride[CPW];
+    bool live[CPW];
+#pragma unroll
+    for (int s = 0; s < CPW; ++s) {
+        const int col = 16 * (wave + NW * s) + lane_c;
+        if (col < n) {
+            src[s] = W + (col_idx ? col_idx[col] : col);
+            stride[s] = ldw;
+            live[s] = true;
+        } else if (col == n && tau != nullptr) {
+            src[s] = tau;
+            stride[s] = 1;
+            live[s] = true;
+        } else {
+            src[s] = W;
+            stride[s] = 0;
+            live[s] = false;
+        }
+    }
+    const long ntiles = (rows + 63) / 64;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long r0 = t * 64;
+        double T[CPW][16];
+#pragma unroll
+        for (int s = 0; s < CPW; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long row = r0 + 16 * (i >> 2) + lane_g + 4 * (i & 3);
+                const bool inb = row < rows;
+                const long rowc = inb ? row : rows - 1;
+                double scale = 1.0;
+                if (blkw) scale = blkw[rowc / rows_per_blk];
+                const double v = src[s][rowc * stride[s]];
+                T[s][i] = (inb && live[s]) ? v * scale : 0.0;
+            }
+        double Rk[CPW], Rn[CPW];
+#pragma unroll
+        for (int s = 0; s < CPW; ++s) {
+            const int col = 16 * (wave + NW * s) + lane_c;
+            Rk[s] = (col < nc && wave + NW * s < nchunks) ? Rg[col] : 0.0;  // row 0
+        }
+        for (int p = 0; p < nchunks; ++p) {
+#define FIGH_WSTEP(KK) \
+    if (16 * p + KK < nc) tsqr_wide_step<KK, CPW>(T, p, nchunks, nc, lane_c, lane_g, wave, xl, Rg, Rk, Rn);
+            FIGH_WSTEP(0) FIGH_WSTEP(1) FIGH_WSTEP(2) FIGH_WSTEP(3) FIGH_WSTEP(4) FIGH_WSTEP(5) FIGH_WSTEP(6)
+            FIGH_WSTEP(7) FIGH_WSTEP(8) FIGH_WSTEP(9) FIGH_WSTEP(10) FIGH_WSTEP(11) FIGH_WSTEP(12) FIGH_WSTEP(13)
+            FIGH_WSTEP(14) FIGH_WSTEP(15)
+#undef FIGH_WSTEP
+        }
+        __syncthreads();  // every wave's row stores of this tile precede the next tile's row loads
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // tsqr_coop_kernel<NCC, NW>: the merge levels.  One workgroup of NW waves factors NW*64 stacked rows (about
 // NW*64/nc triangles) in ONE sweep of column steps instead of NW sequential 64-row tiles: every wave keeps its
 // own 64-row tile in registers, forms its part of x^T B, and the per-wave partial sums are combined through LDS
@@ -952,7 +1109,15 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
         hipLaunchKernelGGL((tsqr2_kernel<5, 4, true, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
                            d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
-    else if (nc <= 128) FIGH_TSQR_LAUNCH(2, 32, false);
+    else if (nc <= 384 && !g_force_v1) {
+        // column-split workgroups: nw here counts workgroups (one private triangle each)
+        if (nc <= 256)
+            hipLaunchKernelGGL((tsqr_wide_kernel<2>), grid, dim3(512), 0, stream(), W, rows, ldw, col_idx, n, tau, d_blkw,
+                               rows_per_blk, Rws_out, nc);
+        else
+            hipLaunchKernelGGL((tsqr_wide_kernel<3>), grid, dim3(512), 0, stream(), W, rows, ldw, col_idx, n, tau, d_blkw,
+                               rows_per_blk, Rws_out, nc);
+    } else if (nc <= 128) FIGH_TSQR_LAUNCH(2, 32, false);
     else if (nc <= 256) FIGH_TSQR_LAUNCH(4, 16, false);
     else if (nc <= 384) FIGH_TSQR_LAUNCH(6, 16, false);
     else {
@@ -1118,6 +1283,7 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     }
     // level 0: one wave per SIMD for the register-resident n <= 64 kernel, fewer for the wide ones
     long target = cu_count() * 2L;
+    if (nc > 80 && !g_force_v1) target = cu_count();  // column-split workgroups of 8 waves: one per CU
     if (nc <= 80 && !g_force_v1) {  // register-tile kernel: as many waves per CU as its LDS triangle admits
         long per_cu = 4;  // tile + prefetched tile in registers: one wave per SIMD
         if (nc <= 64 && g_force_v2 && !g_pf) {
