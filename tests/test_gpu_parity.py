@@ -396,3 +396,53 @@ def test_tx40_real_data_known_answers_hip(lib):
     assert np.abs(phi_w - csvv[:, 2]).max() <= 4e-4
     ok = z["std_wls"] < 1e3
     assert (np.abs(std_w - z["std_wls"])[ok] / z["std_wls"][ok]).max() <= 2e-3
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 49, 63, 64, 65, 79, 80, 81, 128, 200, 257])
+@pytest.mark.parametrize("rows", [1, 63, 64, 65, 1000, 20011])
+def test_tsqr_shapes_against_lapack(lib, n, rows):
+    """Every kernel family / boundary of figh_tsqr (1 wave, tsqr2 4 and 5 chunks, column-split workgroups) on
+    random full-rank matrices: R^T R = A^T A, |diag R| equals LAPACK's when rows >= n; tau column; row weights."""
+    from figaroh_plus_amd.tools.qrdecomposition import rfactor
+    rng = np.random.default_rng(1000 * n + rows)
+    A = rng.standard_normal((rows, n)) * rng.uniform(0.5, 20.0, n)
+    R = rfactor(A)
+    assert R.shape == (n, n) and np.array_equal(R, np.triu(R))
+    G = A.T @ A
+    assert np.abs(R.T @ R - G).max() <= 1e-12 * np.abs(G).max()
+    if rows >= n:
+        ref = np.linalg.qr(A, mode="r")
+        assert np.abs(np.abs(np.diag(R)) - np.abs(np.diag(ref))).max() <= 1e-9 * np.abs(np.diag(ref)).max()
+    if rows >= n + 1 and rows % 7 == 0 or rows == 1000:
+        t = rng.standard_normal(rows)
+        w = rng.uniform(0.5, 2.0, 8 if rows % 8 == 0 else 1)
+        Ra = rfactor(A, tau=t, block_weight=w)
+        scale = np.repeat(w, rows // len(w))
+        As = np.c_[A, t] * scale[:, None]
+        Ga = As.T @ As
+        assert np.abs(Ra.T @ Ra - Ga).max() <= 1e-12 * np.abs(Ga).max()
+
+
+def test_regressor_leading_dimension_and_colsq(lib, golden_ur10):
+    """ldw > ncols (padded rows, scalar store path) and the fused column norms against figh_colsq."""
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.tools.regressor import regressor_flags
+    g = golden_ur10
+    robot = g.robot()
+    q, v, a = g["q_big"], g["v_big"], g["a_big"]
+    N, ldw = len(q), 91
+    dq, dv, da = (_lib.DeviceArray.from_host(np.ascontiguousarray(x).reshape(-1)) for x in (q, v, a))
+    dW = _lib.DeviceArray.from_host(np.full(6 * N * ldw, -7.0))
+    dcs = _lib.DeviceArray((84,))
+    mode, flags, ft = regressor_flags(g.param)
+    _lib.regressor_build(robot.device_model(), mode, flags, ft, N, dq, dv, da, dW, ldw, dcs)
+    Wp = dW.to_host().reshape(6 * N, ldw)
+    assert np.all(Wp[:, 84:] == -7.0)                       # padding untouched
+    ref = _gpu_W(g, q, v, a)
+    assert np.array_equal(Wp[:, :84], ref)
+    cs = dcs.to_host()
+    d2 = _lib.DeviceArray((84,))
+    _lib.colsq(dW, 6 * N, 84, ldw, d2)
+    assert np.abs(cs - d2.to_host()).max() <= 1e-13 * cs.max()
+    with pytest.raises(_lib.FighError):
+        _lib.regressor_build(robot.device_model(), mode, flags, ft, N, dq, dv, da, dW, 80, None)  # ldw < ncols
