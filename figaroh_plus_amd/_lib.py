@@ -157,8 +157,9 @@ class DeviceArray:
             pass
 
 
-def profile_enable(on=True):
-    check(load().figh_profile_enable(1 if on else 0))
+def profile_enable(on=True, level=2):
+    """level 1: dominant kernels only (cheap, usable inside a timed region); level 2: every launch."""
+    check(load().figh_profile_enable(int(level) if on else 0))
 
 
 def profile_reset():

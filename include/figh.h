@@ -60,6 +60,8 @@ int figh_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes);
 int figh_memset(void *d_dst, int value, size_t bytes);
 int figh_synchronize(void);
 /* per-kernel live timing with hipEvents on the library stream (bench.py roofline): enable, run, then query.
+ * figh_profile_enable(level): 0 off; 1 times only the dominant kernels ("regressor_chain" / "regressor_tree" /
+ * "tsqr": a few event records per pass, cheap enough to stay on inside a timed region); 2 times every launch.
  * figh_profile_get: name is the kernel family ("regressor_chain", "regressor_tree", "tsqr", "colsq", ...);
  * returns launches and total milliseconds since the last figh_profile_reset(). */
 int figh_profile_enable(int on);
