@@ -48,7 +48,7 @@ template <int K>
 __device__ __forceinline__ double row_bcast(double x) {  // value of lane-column K of my row group
     // v_mov_b64_dpp: gfx90a+ allows 64-bit DPP for row_newbcast, one instruction per double
     return __longlong_as_double(
-        __builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(x), 0x150 + K, 0xf, 0xf, false));
+        __builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(x), 0x150 + K, 0xf, 0xf, true));
 }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double allreduce_rowgroups(double x) {  // sum over lanes c, c+16, c+32, c+48
@@ -79,36 +79,39 @@ struct Tsqr2State {
 
 // TRI: the tile is one upper-triangular R factor (merge levels): rows 16 rc .. are zero in the columns of panels
 // p < rc, so row chunks rc > p take no part in panel p (neither in the pivot column nor in the update).
-template <int KK, int NCC, int NRC, bool TRI>
-__device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p, const int live) {
+// The panel index P is a compile-time constant: the chunk registers T[P .. NCC-1] are addressed statically (no
+// rotation copies), the number of live chunks is known, and a step is straight-line code -- after the pivot chunk's
+// own dot product (the only input of the Householder scalars) the dot products of the trailing chunks and the LDS
+// reads of row k are independent of the rsq/rcp chain and are interleaved with it by the scheduler.
+template <int KK, int P, int NCC, int NRC, bool TRI>
+__device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
     constexpr int RPL = 4 * NRC;
-    // packed triangle: panel p keeps 16 rows of 16*(NCC-p) entries (columns 16p ..), see tsqr2_rbase
-    const int rowoff = 256 * (p * NCC - (p * (p - 1)) / 2) + KK * 16 * (NCC - p);
-    double x[RPL];
+    constexpr int LIVE = NCC - P;
+    constexpr int NR = TRI ? (4 * (P + 1) < RPL ? 4 * (P + 1) : RPL) : RPL;  // rows per lane that take part
+    // packed triangle: panel p keeps 16 rows of 16*(NCC-p) entries (columns 16p ..)
+    constexpr int rowoff = 256 * (P * NCC - (P * (P - 1)) / 2) + KK * 16 * LIVE;
+    double x[NR];
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) x[i] = (!TRI || (i >> 2) <= p) ? row_bcast<KK>(S.T[0][i]) : 0.0;
-    double d[NCC];
+    for (int i = 0; i < NR; ++i) x[i] = row_bcast<KK>(S.T[P][i]);
+    double Rk[LIVE], d[LIVE];
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
-        d[cc] = 0.0;
-        if (cc < live) {
-            double s0 = 0.0, s1 = 0.0;
+    for (int cc = 0; cc < LIVE; ++cc) Rk[cc] = S.Rl[rowoff + 16 * cc + S.lane_c];
+    {
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < RPL; i += 2) {
-                if (!TRI || (i >> 2) <= p) {
-                    s0 += x[i] * S.T[cc][i];
-                    s1 += x[i + 1] * S.T[cc][i + 1];
-                }
-            }
-            d[cc] = allreduce_rowgroups(s0 + s1);
+        for (int i = 0; i < NR; i += 2) {
+            s0 += x[i] * S.T[P][i];
+            s1 += x[i + 1] * S.T[P][i + 1];
         }
+        d[0] = allreduce_rowgroups(s0 + s1);
     }
-    const double sigma = uniform_of(row_bcast<KK>(d[0]));
-    if (sigma == 0.0) return;  // pivot column already zero below the triangle: H = I (LAPACK dlarfg)
-    double Rk[NCC];
+    // row k of the triangle is requested before the dot product and pinned here, so that the LDS latency is not
+    // part of the dependent chain below (the compiler would otherwise sink the read below the sigma branch)
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) Rk[cc] = cc < live ? S.Rl[rowoff + 16 * cc + S.lane_c] : 0.0;
-    const double alpha = uniform_of(row_bcast<KK>(Rk[0]));
+    for (int cc = 0; cc < LIVE; ++cc) asm volatile("" : "+v"(Rk[cc]));
+    const double alpha = row_bcast<KK>(Rk[0]);   // identical in all lanes (kept in VGPRs: no SGPR round trip)
+    const double sigma = row_bcast<KK>(d[0]);
+    if (uniform_of(sigma) == 0.0) return;  // pivot column already zero below the triangle: H = I (LAPACK dlarfg)
     // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
     // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds + Newton steps instead of the
     // IEEE sqrt and two divisions (a 250-cycle dependent chain per column otherwise)
@@ -126,18 +129,38 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S, const int p,
     const double inv = copysign(ri, alpha);
     const double tfac = dsum * rs;
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
-        if (cc < live) {
-            const bool trail = cc > 0 || S.lane_c > KK;
-            const double wj = trail ? (Rk[cc] + d[cc] * inv) * tfac : 0.0;
-            const double cj = wj * inv;
-            const double rnew = (cc == 0 && S.lane_c == KK) ? beta : Rk[cc] - wj;
+    for (int cc = 1; cc < LIVE; ++cc) {
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < RPL; ++i)
-                if (!TRI || (i >> 2) <= p) S.T[cc][i] -= cj * x[i];
-            if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = rnew;
+        for (int i = 0; i < NR; i += 2) {
+            s0 += x[i] * S.T[P + cc][i];
+            s1 += x[i + 1] * S.T[P + cc][i + 1];
         }
+        d[cc] = allreduce_rowgroups(s0 + s1);
     }
+#pragma unroll
+    for (int cc = 0; cc < LIVE; ++cc) {
+        const bool trail = cc > 0 || S.lane_c > KK;
+        const double wj = trail ? (Rk[cc] + d[cc] * inv) * tfac : 0.0;
+        const double cj = wj * inv;
+        const double rnew = (cc == 0 && S.lane_c == KK) ? beta : Rk[cc] - wj;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) S.T[P + cc][i] -= cj * x[i];
+        if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = rnew;
+    }
+}
+
+// all column steps of panel P, then the next panel (compile-time recursion over the panels)
+template <int P, int NCC, int NRC, bool TRI>
+__device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC> &S, const int first_nz) {
+    if (16 * P + 15 >= first_nz) {
+#define FIGH_STEP(KK) \
+    if (16 * P + KK >= first_nz) tsqr2_step<KK, P, NCC, NRC, TRI>(S);
+        FIGH_STEP(0) FIGH_STEP(1) FIGH_STEP(2) FIGH_STEP(3) FIGH_STEP(4) FIGH_STEP(5) FIGH_STEP(6) FIGH_STEP(7)
+        FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
+#undef FIGH_STEP
+    }
+    if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, TRI>(S, first_nz);
 }
 
 template <int NCC, int NRC, bool PF, bool TRI>
@@ -149,8 +172,8 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
                                                    const int out_rows) {
     // out_rows: row stride of the triangles written to Rws (nc = compact; 64 = one zero-padded R per 64-row tile,
     // the input format of the TRI merge levels)
-    constexpr int RPL = 4 * NRC, M = 16 * NRC, LDR = 16 * NCC;
-    extern __shared__ __attribute__((aligned(16))) double Rl[];  // packed triangle, tsqr2_lds_doubles(nc) entries
+    constexpr int RPL = 4 * NRC, M = 16 * NRC;
+    extern __shared__ __attribute__((aligned(16))) double Rl[];  // packed triangle of the NCC panels
     const int lane = threadIdx.x;
     const long wave = blockIdx.x;
     // Tiles are dealt round-robin (tile t -> wave t mod nwaves): in the joint-major row order the number of
@@ -160,20 +183,22 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
     const long tstep = gridDim.x;
     const long rend = rows;
     (void)rows_per_wave;
+    // The nc columns are RIGHT-aligned in the 16*NCC lane-columns (pad = 16 NCC - nc zero columns in front): a chunk
+    // takes part in every step up to its last column, so the partially filled chunk must be the FIRST one -- for
+    // nc = 50 the chunk holding 2 real columns is then live for 2 steps instead of 50 (-33 % chunk-steps on UR10).
+    const int pad = 16 * NCC - nc;
     Tsqr2State<NCC, NRC> S;
     S.Rl = Rl;
     S.lane_c = lane & 15;
     S.lane_g = lane >> 4;
     S.nc = nc;
-    const int np = (nc + 15) >> 4;  // panels
-
     const double *src[NCC];
     long stride[NCC];
     bool livecol[NCC];
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc) {
-        const int col = 16 * cc + S.lane_c;
-        if (col < n) {
+        const int col = 16 * cc + S.lane_c - pad;
+        if (col >= 0 && col < n) {
             src[cc] = W + (col_idx ? col_idx[col] : col);
             stride[cc] = ldw;
             livecol[cc] = true;
@@ -188,8 +213,7 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
         }
     }
     {
-        const int npan = (nc + 15) >> 4;
-        const int tot = 256 * (npan * NCC - (npan * (npan - 1)) / 2);
+        constexpr int tot = 256 * (NCC * NCC - (NCC * (NCC - 1)) / 2);
         for (int e = lane; e < tot; e += 64) Rl[e] = 0.0;
     }
     __syncthreads();
@@ -202,8 +226,8 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
     int loff[NCC];
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc) {
-        const int col = 16 * cc + S.lane_c;
-        loff[cc] = col < n ? (int)(S.lane_g * ldw) + (col_idx ? col_idx[col] : col) : 0;
+        const int col = 16 * cc + S.lane_c - pad;
+        loff[cc] = (col >= 0 && col < n) ? (int)(S.lane_g * ldw) + (col_idx ? col_idx[col] : col) : 0;
     }
     const bool small_ld = ldw < (1L << 28);
     double Tn[NCC][RPL];
@@ -260,34 +284,21 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
         if constexpr (PF) {
             if (t + tstep < ntiles) request_tile((t + tstep) * M);
         }
-        int first_nz = nc;
+        int first_nz = 16 * NCC;  // in padded lane-column positions
         if (nzlo) first_nz = __ffsll((long long)nzlo) - 1;
         else if (nzhi) first_nz = 64 + __ffs((int)nzhi) - 1;
 
-        for (int p = 0; p < ((dbg & 1) ? 0 : np); ++p) {
-            const int live = NCC - p;
-            if (16 * p + 15 >= first_nz) {
-#define FIGH_STEP(KK)                                                                     \
-    if (16 * p + KK >= first_nz && 16 * p + KK < nc) tsqr2_step<KK, NCC, NRC, TRI>(S, p, live);
-                FIGH_STEP(0) FIGH_STEP(1) FIGH_STEP(2) FIGH_STEP(3) FIGH_STEP(4) FIGH_STEP(5) FIGH_STEP(6) FIGH_STEP(7)
-                FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
-#undef FIGH_STEP
-            }
-            // rotate: the next panel becomes slot 0
-#pragma unroll
-            for (int cc = 0; cc + 1 < NCC; ++cc)
-#pragma unroll
-                for (int i = 0; i < RPL; ++i) S.T[cc][i] = S.T[cc + 1][i];
-        }
+        if (!(dbg & 1)) tsqr2_panels<0, NCC, NRC, TRI>(S, first_nz);
     }
     __syncthreads();
     double *Rg = Rws + wave * (long)out_rows * nc;
     for (int e = lane; e < out_rows * nc; e += 64) {
         const int k = e / nc, col = e - k * nc;
-        const int pk = k >> 4;
-        Rg[e] = (k >= nc || col < 16 * pk)
+        const int kp = k + pad, colp = col + pad;  // padded positions
+        const int pk = kp >> 4;
+        Rg[e] = (k >= nc || colp < 16 * pk)
                     ? 0.0
-                    : Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (k & 15) * 16 * (NCC - pk) + (col - 16 * pk)];
+                    : Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (kp & 15) * 16 * (NCC - pk) + (colp - 16 * pk)];
     }
 }
 
@@ -1092,8 +1103,7 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
         hipLaunchKernelGGL((tsqr3_kernel<5, false>), grid, block, sizeof(double) * nc * 80 + lds3_extra, stream(), W, rows,
                            ldw, col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg);
     } else if (nc <= 64 && !g_force_v1) {
-        const int npan = (nc + 15) >> 4;
-        const size_t lds2 = sizeof(double) * 256 * (npan * 4 - (npan * (npan - 1)) / 2);
+        const size_t lds2 = sizeof(double) * 256 * (4 * 4 - (4 * 3) / 2);  // packed triangle of all 4 panels
         if (tri)
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
                                tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
@@ -1104,8 +1114,7 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
                                tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 80 && !g_force_v1) {
-        const int npan = (nc + 15) >> 4;
-        const size_t lds2 = sizeof(double) * 256 * (npan * 5 - (npan * (npan - 1)) / 2);
+        const size_t lds2 = sizeof(double) * 256 * (5 * 5 - (5 * 4) / 2);
         hipLaunchKernelGGL((tsqr2_kernel<5, 4, true, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
                            d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
