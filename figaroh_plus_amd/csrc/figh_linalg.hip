@@ -20,6 +20,7 @@
 // (a 16-wide Householder panel would leave the matrix pipe waiting on the panel's reductions) the wave-level
 // VALU formulation is used; the roofline this kernel is priced against is that fp64 peak.
 #include <cstdlib>
+#include <type_traits>
 
 #include "figh_internal.h"
 
@@ -150,9 +151,11 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
     }
 }
 
-// all column steps of panel P, then the next panel (compile-time recursion over the panels)
-template <int P, int NCC, int NRC, bool TRI>
-__device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC> &S, const int first_nz) {
+// all column steps of panel P, then the next panel (compile-time recursion over the panels).  after(P) runs when
+// chunk P is retired (its registers are dead for the rest of the tile): the kernel requests the next tile's chunk P
+// into them there.
+template <int P, int NCC, int NRC, bool TRI, class AfterPanel>
+__device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC> &S, const int first_nz, AfterPanel &&after) {
     if (16 * P + 15 >= first_nz) {
 #define FIGH_STEP(KK) \
     if (16 * P + KK >= first_nz) tsqr2_step<KK, P, NCC, NRC, TRI>(S);
@@ -160,18 +163,17 @@ __device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC> &S, const int 
         FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
 #undef FIGH_STEP
     }
-    if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, TRI>(S, first_nz);
+    after(std::integral_constant<int, P>{});
+    if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, TRI>(S, first_nz, after);
 }
 
-template <int NCC, int NRC, bool PF, bool TRI>
-__global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__restrict__ W, const long rows, const long ldw,
-                                                   const int *__restrict__ col_idx, const int n,
-                                                   const double *__restrict__ tau, const double *__restrict__ blkw,
-                                                   const long rows_per_blk, const long rows_per_wave,
-                                                   double *__restrict__ Rws, const int nc, const int dbg,
-                                                   const int out_rows) {
+template <int NCC, int NRC, bool TRI>
+__global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
+    const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
+    const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
+    double *__restrict__ Rws, const int nc, const int dbg, const int out_rows) {
     // out_rows: row stride of the triangles written to Rws (nc = compact; 64 = one zero-padded R per 64-row tile,
-    // the input format of the TRI merge levels)
+    // the input format of the TRI merge levels).  dbg & 1: loads only, no factorisation (ablation).
     constexpr int RPL = 4 * NRC, M = 16 * NRC;
     extern __shared__ __attribute__((aligned(16))) double Rl[];  // packed triangle of the NCC panels
     const int lane = threadIdx.x;
@@ -179,10 +181,9 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
     // Tiles are dealt round-robin (tile t -> wave t mod nwaves): in the joint-major row order the number of
     // non-zero leading columns, hence the work per tile, depends on the joint block, and contiguous ranges
     // would leave the waves of the last joints idle while those of joint 1 finish.
-    const long ntiles = (rows + 16 * NRC - 1) / (16 * NRC);
+    const long ntiles = (rows + M - 1) / M;
     const long tstep = gridDim.x;
     const long rend = rows;
-    (void)rows_per_wave;
     // The nc columns are RIGHT-aligned in the 16*NCC lane-columns (pad = 16 NCC - nc zero columns in front): a chunk
     // takes part in every step up to its last column, so the partially filled chunk must be the FIRST one -- for
     // nc = 50 the chunk holding 2 real columns is then live for 2 steps instead of 50 (-33 % chunk-steps on UR10).
@@ -192,103 +193,111 @@ __global__ __launch_bounds__(64, PF ? 1 : 2) void tsqr2_kernel(const double *__r
     S.lane_c = lane & 15;
     S.lane_g = lane >> 4;
     S.nc = nc;
-    const double *src[NCC];
-    long stride[NCC];
-    bool livecol[NCC];
+    // per-lane column sources: W[:, col_idx[col]] for col < n; tau is column n = nc - 1, i.e. lane-column 15 of the
+    // last chunk; everything else (padding) is a dead lane-column whose registers stay exactly zero for the whole
+    // kernel (zero data, zero R row entry => w_j = c_j = 0 in every step), so they are zeroed once and never loaded.
+    bool wlive[NCC];
+    int cidx[NCC], loff[NCC];
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc) {
         const int col = 16 * cc + S.lane_c - pad;
-        if (col >= 0 && col < n) {
-            src[cc] = W + (col_idx ? col_idx[col] : col);
-            stride[cc] = ldw;
-            livecol[cc] = true;
-        } else if (col == n && tau != nullptr) {
-            src[cc] = tau;
-            stride[cc] = 1;
-            livecol[cc] = true;
-        } else {
-            src[cc] = W;
-            stride[cc] = 0;
-            livecol[cc] = false;
-        }
+        wlive[cc] = col >= 0 && col < n;
+        cidx[cc] = wlive[cc] ? (col_idx ? col_idx[col] : col) : 0;
+        loff[cc] = (int)(S.lane_g * ldw) + cidx[cc];  // the host side guarantees ldw < 2^24
     }
+    const bool tau_lane = tau != nullptr && S.lane_c == 15;
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) S.T[cc][i] = 0.0;
     {
         constexpr int tot = 256 * (NCC * NCC - (NCC * (NCC - 1)) / 2);
         for (int e = lane; e < tot; e += 64) Rl[e] = 0.0;
     }
     __syncthreads();
 
-    // Raw tile loads: lane (g, c) takes rows r0 + 16 rc + g + 4 reg.  Unconditional clamped loads with no dependent
-    // instruction, so all 16*NCC requests of a tile are in flight at once; the NEXT tile is requested before the
-    // current one is factored (software prefetch: one wave per SIMD hides HBM latency by itself).
-    // Full tiles use a wave-uniform row base (SGPR pair) + a 32-bit per-lane element offset g*ldw + column, so the
-    // 16*NCC requests need NCC address registers instead of 16*NCC 64-bit pointers; tau is fetched at delivery.
-    int loff[NCC];
+    // Tile loads: lane (g, c) takes rows r0 + 16 rc + g + 4 reg of its column.  Full tiles use a wave-uniform row base
+    // (SGPR pair) + a 32-bit per-lane element offset g*ldw + column: 16*NCC independent requests, all in flight at
+    // once, under one EXEC mask per chunk.  The requests for the NEXT tile's chunk P are issued as soon as panel P of
+    // the current tile is finished (its registers are dead from then on), so most of a tile's HBM latency is covered
+    // by the wave's own remaining panels and only the last chunk (+ tau) is requested at the top of the iteration.
+    auto load_chunk = [&](auto CC, const long r0) {
+        constexpr int cc = decltype(CC)::value;
+        if (wlive[cc]) {
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
-        const int col = 16 * cc + S.lane_c - pad;
-        loff[cc] = (col >= 0 && col < n) ? (int)(S.lane_g * ldw) + (col_idx ? col_idx[col] : col) : 0;
-    }
-    const bool small_ld = ldw < (1L << 28);
-    double Tn[NCC][RPL];
-    auto request_tile = [&](const long r0) {
-        if (small_ld && r0 + M <= rend && !(dbg & 2)) {
+            for (int i = 0; i < RPL; ++i) S.T[cc][i] = (W + (r0 + 16 * (i >> 2) + 4 * (i & 3)) * ldw)[loff[cc]];
+        }
+    };
+    auto load_head_chunks = [&](const long r0) {  // chunks 0 .. NCC-2
+        if constexpr (NCC > 1) load_chunk(std::integral_constant<int, 0>{}, r0);
+        if constexpr (NCC > 2) load_chunk(std::integral_constant<int, 1>{}, r0);
+        if constexpr (NCC > 3) load_chunk(std::integral_constant<int, 2>{}, r0);
+        if constexpr (NCC > 4) load_chunk(std::integral_constant<int, 3>{}, r0);
+    };
+
+    bool prefetched = false;
+    for (long t = wave; t < ntiles; t += tstep) {
+        const long r0 = t * M;
+        const long r0n = (t + tstep) * M;
+        const bool fast = r0 + M <= rend;
+        const bool next_fast = r0n + M <= rend;
+        if (fast) {
+            if (!prefetched) load_head_chunks(r0);
+            load_chunk(std::integral_constant<int, NCC - 1>{}, r0);
+            if (tau_lane) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) S.T[NCC - 1][i] = (tau + r0 + 16 * (i >> 2) + 4 * (i & 3))[S.lane_g];
+            }
+        } else {  // the last, partial tile: rows clamped to the last one, then masked
+            const double *tb = W + r0 * ldw;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                const double *rowbase = W + (r0 + 16 * (i >> 2) + 4 * (i & 3)) * ldw;
+                const int rr = 16 * (i >> 2) + S.lane_g + 4 * (i & 3);
+                const bool inb = r0 + rr < rend;
+                const int rel = inb ? rr : (int)(rend - 1 - r0);
+                const int ro = rel * (int)ldw;
 #pragma unroll
-                for (int cc = 0; cc < NCC; ++cc) Tn[cc][i] = rowbase[loff[cc]];
+                for (int cc = 0; cc < NCC; ++cc) {
+                    double v = 0.0;
+                    if (wlive[cc]) v = tb[ro + cidx[cc]];
+                    if (cc == NCC - 1 && tau_lane) v = tau[r0 + rel];
+                    S.T[cc][i] = inb ? v : 0.0;
+                }
             }
-            return;
         }
-#pragma unroll
-        for (int cc = 0; cc < NCC; ++cc)
+        if (blkw) {  // row-block weights (WLS): row r is scaled by blkw[r / rows_per_blk]
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const long row = r0 + 16 * (i >> 2) + S.lane_g + 4 * (i & 3);
-                const long rowc = row < rend ? row : rend - 1;
-                Tn[cc][i] = (dbg & 2) ? 1.0 + (double)(cc * RPL + i + lane)
-                                      : (stride[cc] == 1 ? 0.0 : src[cc][rowc * stride[cc]]);
+                const double scale = blkw[(row < rend ? row : rend - 1) / rows_per_blk];
+#pragma unroll
+                for (int cc = 0; cc < NCC; ++cc) S.T[cc][i] *= scale;
             }
-    };
-    if constexpr (PF) {
-        if (wave < ntiles) request_tile(wave * M);
-    }
-
-    for (long t = wave; t < ntiles; t += tstep) {
-        const long r0 = t * M;
-        if constexpr (!PF) request_tile(r0);  // two waves per SIMD: the other wave's factorisation hides this latency
-        // ---- take delivery of the requested tile: row masking, optional row-block weights, zero-column map
-        unsigned long long nzlo = 0;  // bit col (<64) set <=> column has a non-zero in this tile
-        unsigned nzhi = 0;            // cols 64..79
+        }
+        // zero-column map of the tile: bit = padded lane-column position with a non-zero entry
+        unsigned long long nzlo = 0;
+        unsigned nzhi = 0;
 #pragma unroll
         for (int cc = 0; cc < NCC; ++cc) {
             bool nz = false;
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) {
-                const long row = r0 + 16 * (i >> 2) + S.lane_g + 4 * (i & 3);
-                const bool inb = row < rend;
-                double scale = 1.0;
-                if (blkw) scale = blkw[(inb ? row : rend - 1) / rows_per_blk];
-                double raw = Tn[cc][i];
-                if (stride[cc] == 1 && !(dbg & 2)) raw = src[cc][inb ? row : rend - 1];  // the tau lane-column
-                const double val = (inb && livecol[cc]) ? raw * scale : 0.0;
-                S.T[cc][i] = val;
-                nz |= (val != 0.0);
-            }
+            for (int i = 0; i < RPL; ++i) nz |= (S.T[cc][i] != 0.0);
             const unsigned long long b = __ballot(nz);
             const unsigned m16 = (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);
             if (cc < 4) nzlo |= (unsigned long long)m16 << (16 * cc);
             else nzhi |= m16 << (16 * (cc - 4));
         }
-        if constexpr (PF) {
-            if (t + tstep < ntiles) request_tile((t + tstep) * M);
-        }
         int first_nz = 16 * NCC;  // in padded lane-column positions
         if (nzlo) first_nz = __ffsll((long long)nzlo) - 1;
         else if (nzhi) first_nz = 64 + __ffs((int)nzhi) - 1;
+        if (dbg & 1) first_nz = 16 * NCC + 16;
 
-        if (!(dbg & 1)) tsqr2_panels<0, NCC, NRC, TRI>(S, first_nz);
+        tsqr2_panels<0, NCC, NRC, TRI>(S, first_nz, [&](auto P) {
+            if constexpr (decltype(P)::value < NCC - 1) {
+                if (next_fast) load_chunk(P, r0n);
+            }
+        });
+        prefetched = next_fast;
     }
     __syncthreads();
     double *Rg = Rws + wave * (long)out_rows * nc;
@@ -1105,18 +1114,15 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
     } else if (nc <= 64 && !g_force_v1) {
         const size_t lds2 = sizeof(double) * 256 * (4 * 4 - (4 * 3) / 2);  // packed triangle of all 4 panels
         if (tri)
-            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
-                               tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
-        else if (g_pf)
-            hipLaunchKernelGGL((tsqr2_kernel<4, 4, true, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
-                               tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
+                               d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
         else
-            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
-                               tau, d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
+                               d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 80 && !g_force_v1) {
         const size_t lds2 = sizeof(double) * 256 * (5 * 5 - (5 * 4) / 2);
-        hipLaunchKernelGGL((tsqr2_kernel<5, 4, true, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
-                           d_blkw, rows_per_blk, rpw, Rws_out, nc, g_dbg, out_rows);
+        hipLaunchKernelGGL((tsqr2_kernel<5, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
+                           d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
     else if (nc <= 384 && !g_force_v1) {
         // column-split workgroups: nw here counts workgroups (one private triangle each)
@@ -1278,6 +1284,7 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     FIGH_REQUIRE(rows > 0 && n > 0 && ldw > 0, "bad shape");
     const int nc = n + (d_tau ? 1 : 0);
     FIGH_REQUIRE(nc <= 384, "figh_tsqr: more than 384 columns not supported yet");
+    FIGH_REQUIRE(ldw < (1L << 24), "figh_tsqr: leading dimension must be below 2^24 elements");
     if (int rc = ensure_device()) return rc;
     const double *d_blkw = nullptr;
     long rows_per_blk = 1;
@@ -1295,13 +1302,8 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     if (nc > 80 && !g_force_v1) target = cu_count();  // column-split workgroups of 8 waves: one per CU
     if (nc <= 80 && !g_force_v1) {  // register-tile kernel: as many waves per CU as its LDS triangle admits
         long per_cu = 4;  // tile + prefetched tile in registers: one wave per SIMD
-        if (nc <= 64 && g_force_v2 && !g_pf) {
-            // unblocked kernel capped at 256 registers: two waves per SIMD when the packed LDS triangles fit
-            const int npan = (nc + 15) >> 4;
-            const size_t lds = sizeof(double) * 256 * (npan * 4 - (npan * (npan - 1)) / 2);
-            per_cu = (long)((160 * 1024) / lds);
-            if (per_cu > 8) per_cu = 8;
-        }
+        if (nc <= 64 && g_force_v2) per_cu = 8;  // 256 registers, 20 KB LDS triangle: two waves per SIMD
+        else if (g_force_v2) per_cu = 5;          // 5 chunks: 30 KB LDS triangle per wave
         target = cu_count() * per_cu;
     } else if (nc <= 64) {
         target = cu_count() * 4L;
