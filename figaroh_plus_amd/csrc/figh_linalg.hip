@@ -20,7 +20,10 @@
 // (a 16-wide Householder panel would leave the matrix pipe waiting on the panel's reductions) the wave-level
 // VALU formulation is used; the roofline this kernel is priced against is that fp64 peak.
 #include <cstdlib>
+#include <algorithm>
+#include <cstdio>
 #include <type_traits>
+#include <vector>
 
 #include "figh_internal.h"
 
@@ -84,6 +87,16 @@ struct Tsqr2State {
 // rotation copies), the number of live chunks is known, and a step is straight-line code -- after the pivot chunk's
 // own dot product (the only input of the Householder scalars) the dot products of the trailing chunks and the LDS
 // reads of row k are independent of the rsq/rcp chain and are interleaved with it by the scheduler.
+// acc += (value of pv in lane-column K of my row group) * b as ONE instruction: gfx90a+ allow a DPP row_newbcast
+// operand on the DP ALU v_fmac_f64, so the pivot column is never materialised in registers (no v_mov_b64_dpp per
+// row, 32 VGPRs less).  The compiler does not form this instruction by itself.  Hazard: a VGPR written by a VALU
+// instruction needs 2 wait states before a DPP read -- every use below reads pivot-chunk registers that were last
+// written in the previous column step, i.e. before that step's closing scalar compare + branch.
+template <int K>
+__device__ __forceinline__ void fmac_bcast(double &acc, const double pv, const double b) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pv), "v"(b), "n"(K));
+}
+
 template <int KK, int P, int NCC, int NRC, bool TRI>
 __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
     constexpr int RPL = 4 * NRC;
@@ -91,20 +104,20 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
     constexpr int NR = TRI ? (4 * (P + 1) < RPL ? 4 * (P + 1) : RPL) : RPL;  // rows per lane that take part
     // packed triangle: panel p keeps 16 rows of 16*(NCC-p) entries (columns 16p ..)
     constexpr int rowoff = 256 * (P * NCC - (P * (P - 1)) / 2) + KK * 16 * LIVE;
-    double x[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) x[i] = row_bcast<KK>(S.T[P][i]);
+    // The pivot column x = lane-column KK of chunk P is read in place through the DPP operand.
     double Rk[LIVE], d[LIVE];
 #pragma unroll
     for (int cc = 0; cc < LIVE; ++cc) Rk[cc] = S.Rl[rowoff + 16 * cc + S.lane_c];
     {
-        double s0 = 0.0, s1 = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four chains: no back-to-back dependent DPP instructions
 #pragma unroll
-        for (int i = 0; i < NR; i += 2) {
-            s0 += x[i] * S.T[P][i];
-            s1 += x[i + 1] * S.T[P][i + 1];
+        for (int i = 0; i < NR; i += 4) {
+            fmac_bcast<KK>(s0, S.T[P][i], S.T[P][i]);
+            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P][i + 1]);
+            fmac_bcast<KK>(s2, S.T[P][i + 2], S.T[P][i + 2]);
+            fmac_bcast<KK>(s3, S.T[P][i + 3], S.T[P][i + 3]);
         }
-        d[0] = allreduce_rowgroups(s0 + s1);
+        d[0] = allreduce_rowgroups((s0 + s1) + (s2 + s3));
     }
     // row k of the triangle is requested before the dot product and pinned here, so that the LDS latency is not
     // part of the dependent chain below (the compiler would otherwise sink the read below the sigma branch)
@@ -112,21 +125,19 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
     for (int cc = 0; cc < LIVE; ++cc) asm volatile("" : "+v"(Rk[cc]));
     const double alpha = row_bcast<KK>(Rk[0]);   // identical in all lanes (kept in VGPRs: no SGPR round trip)
     const double sigma = row_bcast<KK>(d[0]);
-    if (uniform_of(sigma) == 0.0) return;  // pivot column already zero below the triangle: H = I (LAPACK dlarfg)
+    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
     // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
     // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds + Newton steps instead of the
-    // IEEE sqrt and two divisions (a 250-cycle dependent chain per column otherwise)
+    // IEEE sqrt and two divisions
     const double q2 = fma(alpha, alpha, sigma);
+    const double hq = -0.5 * q2;
     double rs = __builtin_amdgcn_rsq(q2);
-    rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
-    rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
-    double sq = q2 * rs;
-    sq = fma(fma(-sq, sq, q2), 0.5 * rs, sq);
-    const double dsum = fabs(alpha) + sq;
+    rs = rs * fma(hq * rs, rs, 1.5);
+    rs = rs * fma(hq * rs, rs, 1.5);
+    const double dsum = fma(q2, rs, fabs(alpha));  // |alpha| + s
     double ri = __builtin_amdgcn_rcp(dsum);
     ri = ri * fma(-dsum, ri, 2.0);
     ri = ri * fma(-dsum, ri, 2.0);
-    const double beta = -copysign(sq, alpha);
     const double inv = copysign(ri, alpha);
     const double tfac = dsum * rs;
 #pragma unroll
@@ -134,20 +145,24 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int i = 0; i < NR; i += 2) {
-            s0 += x[i] * S.T[P + cc][i];
-            s1 += x[i + 1] * S.T[P + cc][i + 1];
+            fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
+            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
         }
         d[cc] = allreduce_rowgroups(s0 + s1);
     }
+    // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
+    //   - the pivot lane itself gets w = (alpha + sigma inv) tfac = alpha - beta, hence R_kk = alpha - w = beta and
+    //     c = w inv = 1: its tile entries x - 1 x vanish (the finished column leaves the tile);
+    //   - finished lane-columns (c < KK) and padding hold zeros (up to rounding residues that are never read as
+    //     results), so their w is zero by itself.
+    // Trailing chunks first, the pivot chunk last: its own update is the only write to the DPP source registers.
 #pragma unroll
-    for (int cc = 0; cc < LIVE; ++cc) {
-        const bool trail = cc > 0 || S.lane_c > KK;
-        const double wj = trail ? (Rk[cc] + d[cc] * inv) * tfac : 0.0;
-        const double cj = wj * inv;
-        const double rnew = (cc == 0 && S.lane_c == KK) ? beta : Rk[cc] - wj;
+    for (int cc = LIVE - 1; cc >= 0; --cc) {
+        const double wj = (Rk[cc] + d[cc] * inv) * tfac;
+        const double ncj = -wj * inv;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) S.T[P + cc][i] -= cj * x[i];
-        if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = rnew;
+        for (int i = 0; i < NR; ++i) fmac_bcast<KK>(S.T[P + cc][i], S.T[P][i], ncj);
+        if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = Rk[cc] - wj;
     }
 }
 
@@ -167,11 +182,14 @@ __device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC> &S, const int 
     if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, TRI>(S, first_nz, after);
 }
 
-template <int NCC, int NRC, bool TRI>
+template <int NCC, int NRC, bool TRI, bool PROF = false>
 __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
     const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
-    double *__restrict__ Rws, const int nc, const int dbg, const int out_rows) {
+    double *__restrict__ Rws, const int nc, const int dbg, const int out_rows, long long *__restrict__ prof = nullptr) {
+    // PROF (FIGH_TSQR_DBG & 4): per-wave s_memtime totals {kernel, load + delivery, factorisation, column steps}
+    long long pc_load = 0, pc_fact = 0, pc_steps = 0;
+    const long long pc_begin = PROF ? (long long)__builtin_readcyclecounter() : 0;
     // out_rows: row stride of the triangles written to Rws (nc = compact; 64 = one zero-padded R per 64-row tile,
     // the input format of the TRI merge levels).  dbg & 1: loads only, no factorisation (ablation).
     constexpr int RPL = 4 * NRC, M = 16 * NRC;
@@ -241,6 +259,7 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
         const long r0n = (t + tstep) * M;
         const bool fast = r0 + M <= rend;
         const bool next_fast = r0n + M <= rend;
+        const long long pc_a = PROF ? (long long)__builtin_readcyclecounter() : 0;
         if (fast) {
             if (!prefetched) load_head_chunks(r0);
             load_chunk(std::integral_constant<int, NCC - 1>{}, r0);
@@ -291,6 +310,7 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
         if (nzlo) first_nz = __ffsll((long long)nzlo) - 1;
         else if (nzhi) first_nz = 64 + __ffs((int)nzhi) - 1;
         if (dbg & 1) first_nz = 16 * NCC + 16;
+        const long long pc_b = PROF ? (long long)__builtin_readcyclecounter() : 0;
 
         tsqr2_panels<0, NCC, NRC, TRI>(S, first_nz, [&](auto P) {
             if constexpr (decltype(P)::value < NCC - 1) {
@@ -298,14 +318,28 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
             }
         });
         prefetched = next_fast;
+        if constexpr (PROF) {
+            const long long pc_c = (long long)__builtin_readcyclecounter();
+            pc_load += pc_b - pc_a;
+            pc_fact += pc_c - pc_b;
+            pc_steps += first_nz < 16 * NCC ? 16 * NCC - first_nz : 0;
+        }
     }
     __syncthreads();
+    if constexpr (PROF) {
+        if (lane == 0 && prof) {
+            prof[4 * wave + 0] = (long long)__builtin_readcyclecounter() - pc_begin;
+            prof[4 * wave + 1] = pc_load;
+            prof[4 * wave + 2] = pc_fact;
+            prof[4 * wave + 3] = pc_steps;
+        }
+    }
     double *Rg = Rws + wave * (long)out_rows * nc;
     for (int e = lane; e < out_rows * nc; e += 64) {
         const int k = e / nc, col = e - k * nc;
         const int kp = k + pad, colp = col + pad;  // padded positions
         const int pk = kp >> 4;
-        Rg[e] = (k >= nc || colp < 16 * pk)
+        Rg[e] = (k >= nc || col < k)  // below the diagonal the LDS rows hold rounding residues, not results
                     ? 0.0
                     : Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (kp & 15) * 16 * (NCC - pk) + (colp - 16 * pk)];
     }
@@ -1116,7 +1150,40 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
         if (tri)
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
                                d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
-        else
+        else if (g_dbg & 4) {
+            long long *prof = static_cast<long long *>(workspace(sizeof(long long) * 4 * nw, 6));
+            if (!prof) return FIGH_ERR_ALLOC;
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
+                               tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, prof);
+            std::vector<long long> h(4 * nw);
+            FIGH_HIP(hipMemcpyAsync(h.data(), prof, sizeof(long long) * 4 * nw, hipMemcpyDeviceToHost, stream()));
+            FIGH_HIP(hipStreamSynchronize(stream()));
+            double tot = 0, ld = 0, fa = 0, st = 0, mx = 0;
+            for (long w = 0; w < nw; ++w) {
+                tot += h[4 * w]; ld += h[4 * w + 1]; fa += h[4 * w + 2]; st += h[4 * w + 3];
+                if (h[4 * w] > mx) mx = h[4 * w];
+            }
+            fprintf(stderr, "[tsqr2 prof] waves %ld rows %ld: ticks/wave avg %.0f max %.0f; load+delivery %.0f; "
+                            "factorisation %.0f; steps/wave %.0f -> %.0f ticks per column step\n",
+                    nw, rows, tot / nw, mx, ld / nw, fa / nw, st / nw, st > 0 ? fa / st : 0.0);
+            if (nw >= 64) {  // by XCD (workgroups are dealt round-robin to the 8 XCDs) and by position in the grid
+                double xs[8] = {0}, xn[8] = {0}, ss[8] = {0};
+                for (long w = 0; w < nw; ++w) { xs[w & 7] += h[4 * w]; ss[w & 7] += h[4 * w + 3]; xn[w & 7] += 1; }
+                fprintf(stderr, "[tsqr2 prof] ticks/wave by XCD:");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f(%.0f steps)", xs[x] / xn[x], ss[x] / xn[x]);
+                fprintf(stderr, "\n[tsqr2 prof] ticks/wave by grid octile:");
+                for (int o = 0; o < 8; ++o) {
+                    double a = 0; long c = 0;
+                    for (long w = o * nw / 8; w < (o + 1) * nw / 8; ++w) { a += h[4 * w]; ++c; }
+                    fprintf(stderr, " %.0f", a / c);
+                }
+                std::vector<long long> d(nw);
+                for (long w = 0; w < nw; ++w) d[w] = h[4 * w];
+                std::sort(d.begin(), d.end());
+                fprintf(stderr, "\n[tsqr2 prof] ticks/wave quantiles: min %lld 10%% %lld 50%% %lld 90%% %lld 99%% %lld max %lld\n",
+                        d[0], d[nw / 10], d[nw / 2], d[nw * 9 / 10], d[nw * 99 / 100], d[nw - 1]);
+            }
+        } else
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
                                d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 80 && !g_force_v1) {
@@ -1304,6 +1371,8 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
         long per_cu = 4;  // tile + prefetched tile in registers: one wave per SIMD
         if (nc <= 64 && g_force_v2) per_cu = 8;  // 256 registers, 20 KB LDS triangle: two waves per SIMD
         else if (g_force_v2) per_cu = 5;          // 5 chunks: 30 KB LDS triangle per wave
+        static const int g_wpc = getenv("FIGH_TSQR_WPC") ? atoi(getenv("FIGH_TSQR_WPC")) : 0;  // A/B: waves per CU
+        if (g_wpc > 0) per_cu = g_wpc;
         target = cu_count() * per_cu;
     } else if (nc <= 64) {
         target = cu_count() * 4L;
