@@ -66,6 +66,17 @@ __device__ __forceinline__ double allreduce_rowgroups(double x) {  // sum over l
     b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
+// The same sum on the matrix pipe: with A = all ones, v_mfma_f64_16x16x4 computes D[m][n] = sum_k B[k][n], and the
+// K index of the B operand IS the row group (lane = 16 k + n), so one MFMA replaces 4 v_mov + 4 v_permlane*_swap
+// (12 ticks each) + 2 v_add_f64.  Measured: NOT faster (1.129 vs 1.107 ms on the UR10 problem) -- the f64 MFMA
+// occupies the FP64 datapath for its 64 ticks (tools/microbench/latency.hip: MFMA + independent v_fma_f64 do not
+// overlap), so it only trades VALU issue slots for FP64-pipe time.  Kept for reference, not used.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double allreduce_rowgroups_mfma(double x) {
+    const f64x4_t zero = {0.0, 0.0, 0.0, 0.0};
+    const f64x4_t r = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, x, zero, 0, 0, 0);
+    return r[0];
+}
 __device__ __forceinline__ double uniform_of(double x) {  // SGPR copy of a value that is identical in all lanes
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
                             __builtin_amdgcn_readfirstlane(__double2loint(x)));
@@ -254,7 +265,18 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     };
 
     bool prefetched = false;
+    // The SIMD arbiter favours the older of its two resident waves, which then finishes ~25 % earlier and leaves
+    // the younger one running alone (at a single wave's issue efficiency) for the rest of the kernel.  The two
+    // halves of the grid therefore alternate their issue priority per tile, in antiphase, so that both waves of a
+    // SIMD progress at a more even rate and the SIMD stays doubly occupied for longer (measured 1.120 -> 1.091 ms;
+    // in the paired phase the SIMD is issue-bound, so this only shortens the single-wave tail).
+    int prio_phase = (dbg & 8) ? -1 : (wave >= tstep / 2 ? 1 : 0);
     for (long t = wave; t < ntiles; t += tstep) {
+        if (prio_phase >= 0) {
+            if (prio_phase & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            ++prio_phase;
+        }
         const long r0 = t * M;
         const long r0n = (t + tstep) * M;
         const bool fast = r0 + M <= rend;
