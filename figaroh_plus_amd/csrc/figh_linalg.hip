@@ -531,72 +531,79 @@ __global__ __launch_bounds__(512) void tsqr_wide_kernel(const double *__restrict
 // (fixed order: bit-reproducible).  A merge level is latency-bound (few waves on the chip), so its time is the
 // number of dependent column steps: nc per level here, against fan*nc for one wave walking `fan` tiles.
 // The triangle being built starts empty (alpha = 0), so row k is final at step k and is written straight out.
-template <int KK, int NCC, int NW>
-__device__ __forceinline__ void tsqr_coop_step(double (&T)[NCC][16], const int p, const int live, const int nc,
-                                               const int lane_c, const int lane_g, const int wave,
-                                               double (*pw)[NW][16 * NCC], double (*tot)[16 * NCC],
+template <int KK, int P, int NCC, int NW>
+__device__ __forceinline__ void tsqr_coop_step(double (&T)[NCC][16], const int nc, const int pad, const int lane_c,
+                                               const int lane_g, const int wave, double (*pw)[NW][16 * NCC],
                                                double *__restrict__ Rg) {
-    const int kabs = 16 * p + KK;
-    const int buf = kabs & 1;
-    double x[16];
+    constexpr int LIVE = NCC - P;
+    constexpr int kpos = 16 * P + KK;  // padded position of the pivot column
+    const int buf = kpos & 1;
+    // per-wave partial dot products of the pivot column (read in place through the DPP operand) with the live chunks
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = row_bcast<KK>(T[0][i]);
+    for (int cc = 0; cc < LIVE; ++cc) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
-        if (cc < live) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                s0 += x[i] * T[cc][i];
-                s1 += x[i + 1] * T[cc][i + 1];
-            }
-            const double dw = allreduce_rowgroups(s0 + s1);
-            if (lane_g == 0) pw[buf][wave][16 * cc + lane_c] = dw;
+        for (int i = 0; i < 16; i += 4) {
+            fmac_bcast<KK>(s0, T[P][i], T[P + cc][i]);
+            fmac_bcast<KK>(s1, T[P][i + 1], T[P + cc][i + 1]);
+            fmac_bcast<KK>(s2, T[P][i + 2], T[P + cc][i + 2]);
+            fmac_bcast<KK>(s3, T[P][i + 3], T[P + cc][i + 3]);
         }
+        const double dw = allreduce_rowgroups((s0 + s1) + (s2 + s3));
+        if (lane_g == 0) pw[buf][wave][16 * (P + cc) + lane_c] = dw;
     }
     __syncthreads();
-    if (wave == 0) {
-        for (int l = 16 * lane_g + lane_c; l < 16 * live; l += 64) {
-            double s = 0.0;
+    // every wave sums the NW partials itself, in wave order (bit-reproducible): one barrier per column step; the
+    // partial buffers ping-pong so that the next step's stores cannot overtake a slow reader of this one
+    double d[LIVE];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += pw[buf][w][l];
-            tot[buf][l] = s;
-        }
+    for (int cc = 0; cc < LIVE; ++cc) {
+        double s = pw[buf][0][16 * (P + cc) + lane_c];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += pw[buf][w][16 * (P + cc) + lane_c];
+        d[cc] = s;
     }
-    __syncthreads();
-    const double sigma = uniform_of(tot[buf][KK]);
-    if (sigma == 0.0) return;  // uniform over the workgroup: every wave read the same total
+    const double sigma = row_bcast<KK>(d[0]);
+    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // uniform over the workgroup: same totals in every wave
+    // the output triangle starts empty, so alpha = 0: beta = -s, v = x / s, tau = 1
+    const double hq = -0.5 * sigma;
     double rs = __builtin_amdgcn_rsq(sigma);
-    rs = rs * fma(-0.5 * sigma * rs, rs, 1.5);
-    rs = rs * fma(-0.5 * sigma * rs, rs, 1.5);
-    double sq = sigma * rs;
-    sq = fma(fma(-sq, sq, sigma), 0.5 * rs, sq);
-    rs = rs * fma(-sq, rs, 2.0);  // 1/s refined against the final s
-    const double beta = -sq;      // alpha = 0: beta = -s, inv = 1/s, tfac = 1
+    rs = rs * fma(hq * rs, rs, 1.5);
+    rs = rs * fma(hq * rs, rs, 1.5);
+    // w_j = x^T B_j / s for every lane-column (no masks): the pivot lane gets w = s, c = 1 and cancels itself, its
+    // R entry is -w = beta; finished and padding lane-columns hold (near) zeros.  Pivot chunk last: DPP source.
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
-        if (cc < live) {
-            const double d = tot[buf][16 * cc + lane_c];
-            const bool trail = cc > 0 || lane_c > KK;
-            const double wj = trail ? d * rs : 0.0;
-            const double cj = wj * rs;
+    for (int cc = LIVE - 1; cc >= 0; --cc) {
+        const double wj = d[cc] * rs;
+        const double ncj = -wj * rs;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) T[cc][i] -= cj * x[i];
-            const int col = 16 * (p + cc) + lane_c;
-            if (wave == 0 && lane_g == 0 && col < nc && (cc > 0 || lane_c >= KK))
-                Rg[(long)kabs * nc + col] = (cc == 0 && lane_c == KK) ? beta : -wj;
-        }
+        for (int i = 0; i < 16; ++i) fmac_bcast<KK>(T[P + cc][i], T[P][i], ncj);
+        const int col = 16 * (P + cc) + lane_c - pad;
+        if (wave == 0 && lane_g == 0 && col >= kpos - pad) Rg[(long)(kpos - pad) * nc + col] = -wj;
     }
+}
+
+template <int P, int NCC, int NW>
+__device__ __forceinline__ void tsqr_coop_panels(double (&T)[NCC][16], const int nc, const int pad, const int lane_c,
+                                                 const int lane_g, const int wave, double (*pw)[NW][16 * NCC],
+                                                 double *__restrict__ Rg) {
+#define FIGH_CSTEP(KK) \
+    if (16 * P + KK >= pad) tsqr_coop_step<KK, P, NCC, NW>(T, nc, pad, lane_c, lane_g, wave, pw, Rg);
+    FIGH_CSTEP(0) FIGH_CSTEP(1) FIGH_CSTEP(2) FIGH_CSTEP(3) FIGH_CSTEP(4) FIGH_CSTEP(5) FIGH_CSTEP(6) FIGH_CSTEP(7)
+    FIGH_CSTEP(8) FIGH_CSTEP(9) FIGH_CSTEP(10) FIGH_CSTEP(11) FIGH_CSTEP(12) FIGH_CSTEP(13) FIGH_CSTEP(14)
+    FIGH_CSTEP(15)
+#undef FIGH_CSTEP
+    if constexpr (P + 1 < NCC) tsqr_coop_panels<P + 1, NCC, NW>(T, nc, pad, lane_c, lane_g, wave, pw, Rg);
 }
 
 template <int NCC, int NW>
 __global__ __launch_bounds__(64 * NW) void tsqr_coop_kernel(const double *__restrict__ Rs, const long rows, const int nc,
                                                             double *__restrict__ Rout) {
     __shared__ double pw[2][NW][16 * NCC];
-    __shared__ double tot[2][16 * NCC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lane_c = lane & 15, lane_g = lane >> 4;
     const long r0 = ((long)blockIdx.x * NW + wave) * 64;
+    const int pad = 16 * NCC - nc;  // columns right-aligned, as in tsqr2_kernel
     double *Rg = Rout + (long)blockIdx.x * nc * nc;
     for (int e = threadIdx.x; e < nc * nc; e += 64 * NW) Rg[e] = 0.0;
     double T[NCC][16];
@@ -605,26 +612,13 @@ __global__ __launch_bounds__(64 * NW) void tsqr_coop_kernel(const double *__rest
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long row = r0 + 16 * (i >> 2) + lane_g + 4 * (i & 3);
-            const int col = 16 * cc + lane_c;
-            const bool ok = row < rows && col < nc;
+            const int col = 16 * cc + lane_c - pad;
+            const bool ok = row < rows && col >= 0;
             const double v = Rs[(ok ? row : 0) * nc + (ok ? col : 0)];
             T[cc][i] = ok ? v : 0.0;
         }
     __syncthreads();  // the zero fill of Rg is ordered before the row stores of wave 0 (same workgroup)
-    const int np = (nc + 15) >> 4;
-    for (int p = 0; p < np; ++p) {
-        const int live = NCC - p;
-#define FIGH_CSTEP(KK) \
-    if (16 * p + KK < nc) tsqr_coop_step<KK, NCC, NW>(T, p, live, nc, lane_c, lane_g, wave, pw, tot, Rg);
-        FIGH_CSTEP(0) FIGH_CSTEP(1) FIGH_CSTEP(2) FIGH_CSTEP(3) FIGH_CSTEP(4) FIGH_CSTEP(5) FIGH_CSTEP(6) FIGH_CSTEP(7)
-        FIGH_CSTEP(8) FIGH_CSTEP(9) FIGH_CSTEP(10) FIGH_CSTEP(11) FIGH_CSTEP(12) FIGH_CSTEP(13) FIGH_CSTEP(14)
-        FIGH_CSTEP(15)
-#undef FIGH_CSTEP
-#pragma unroll
-        for (int cc = 0; cc + 1 < NCC; ++cc)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) T[cc][i] = T[cc + 1][i];
-    }
+    tsqr_coop_panels<0, NCC, NW>(T, nc, pad, lane_c, lane_g, wave, pw, Rg);
 }
 
 // ------------------------------------------------------------------------------------------------------------
