@@ -54,6 +54,14 @@ SIGNATURES = {
     "figh_tsqr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int,
                             C.c_void_p]),
     "figh_tsqr_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "figh_regressor_colsq": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p]),
+    "figh_regressor_tsqr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int, C.c_int64,
+                                      C.c_void_p]),
+    "figh_regressor_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _c_double_p, _c_double_p,
+                                      _c_double_p]),
     "figh_comm_unique_id": (C.c_int, [C.c_void_p]),
     "figh_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "figh_comm_destroy": (C.c_int, []),
@@ -251,6 +259,35 @@ def tsqr(d_W, rows, ldw, d_idx, n, d_tau, block_weight, d_R):
         nb = len(bwa)
     check(load().figh_tsqr(d_W.ptr, rows, ldw, d_idx.ptr if d_idx is not None else None, n,
                            d_tau.ptr if d_tau is not None else None, bw, nb, d_R.ptr))
+
+
+def regressor_colsq(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_colsq, chunk_samples=0):
+    check(load().figh_regressor_colsq(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr, chunk_samples,
+                                      d_colsq.ptr))
+
+
+def regressor_tsqr(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau, block_weight, d_R, chunk_samples=0):
+    bw, nb = None, 0
+    if block_weight is not None:
+        bwa = _f64(block_weight)
+        bw, nb = bwa.ctypes.data_as(_c_double_p), len(bwa)
+    check(load().figh_regressor_tsqr(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr,
+                                     d_idx.ptr if d_idx is not None else None, n,
+                                     d_tau.ptr if d_tau is not None else None, bw, nb, chunk_samples, d_R.ptr))
+
+
+def regressor_gram(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau=None, chunk_samples=0):
+    """(G, g, tau_sq): W_e^T W_e, W_e^T tau, tau^T tau (g, tau_sq None without tau)."""
+    G = np.empty((n, n))
+    g = np.empty(n) if d_tau is not None else None
+    tt = C.c_double(0.0)
+    check(load().figh_regressor_gram(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr,
+                                     d_idx.ptr if d_idx is not None else None, n,
+                                     d_tau.ptr if d_tau is not None else None, chunk_samples,
+                                     G.ctypes.data_as(_c_double_p),
+                                     g.ctypes.data_as(_c_double_p) if g is not None else None,
+                                     C.byref(tt) if d_tau is not None else None))
+    return G, g, (tt.value if d_tau is not None else None)
 
 
 def tsqr_merge(d_Rs, count, nc, d_R):

@@ -1,0 +1,135 @@
+// Streamed ("fused" in SURVEY.md section 8b) entry points: the stacked regressor is never materialised in full.
+// The samples are cut into chunks; each chunk's W lives in a library workspace just long enough for the next kernel
+// (column norms, or the level-0 Householder TSQR) and is then overwritten by the next chunk.  This is what makes the
+// human model at 1e7 samples (269 GB of W) or any W beyond HBM tractable, and it is the C-ABI form of
+// IdentificationPipeline(chunk_samples=...).
+//
+//   figh_regressor_colsq  : diag(W^T W) of build_regressor_basic's W               (regressor.py:243,271)
+//   figh_regressor_tsqr   : R of np.linalg.qr(W[:, col_idx] | tau), optionally row-block weighted
+//                                                                                   (qrdecomposition.py:105,205,238)
+//   figh_regressor_gram   : W_e^T W_e, W_e^T tau, tau^T tau from that R (host, O(n^3)) -- the normal-equation
+//                           quantities of the SIP QP (identification_tools.py:528-531) and of collective (1) in
+//                           SURVEY.md section 8e, without squaring the condition number on the way.
+#include <vector>
+
+#include "figh_internal.h"
+
+using namespace figh;
+
+namespace {
+
+__global__ __launch_bounds__(256) void vec_add_kernel(double *__restrict__ acc, const double *__restrict__ x, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
+
+int64_t default_chunk(int rps, int ncols) {
+    // ~2 GB of W per chunk: large enough to fill the chip (2048 waves x >= 8 tiles), small next to 288 GB
+    int64_t c = (int64_t)(2.0e9 / (8.0 * rps * ncols));
+    c = (c / 64) * 64;
+    return c < 64 ? 64 : c;
+}
+
+}  // namespace
+
+extern "C" int figh_regressor_colsq(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                                    const double *d_v, const double *d_a, int64_t chunk_samples, double *d_colsq) {
+    int rps = 0, ncols = 0;
+    if (int rc = figh_regressor_shape(model, mode, flags, &rps, &ncols)) return rc;
+    FIGH_REQUIRE(N >= 0 && chunk_samples >= 0, "negative size");
+    FIGH_REQUIRE(d_q && d_v && d_a && d_colsq, "NULL device pointer");
+    if (int rc = ensure_device()) return rc;
+    FIGH_HIP(hipMemsetAsync(d_colsq, 0, sizeof(double) * ncols, stream()));
+    if (N == 0) return FIGH_OK;
+    if (chunk_samples == 0) chunk_samples = default_chunk(rps, ncols);
+    const int64_t cs = chunk_samples < N ? chunk_samples : N;
+    double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs * ncols, 8));
+    double *part = static_cast<double *>(workspace(sizeof(double) * ncols, 9));
+    if (!Wc || !part) return FIGH_ERR_ALLOC;
+    const int nq = model->host.nq, nv = model->host.nv;
+    for (int64_t lo = 0; lo < N; lo += cs) {
+        const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
+        if (int rc = figh_regressor_build(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv, d_a + lo * nv, Wc,
+                                          ncols, part))
+            return rc;
+        hipLaunchKernelGGL(vec_add_kernel, dim3((ncols + 255) / 256), dim3(256), 0, stream(), d_colsq, part, ncols);
+        FIGH_HIP(hipGetLastError());
+    }
+    return FIGH_OK;
+}
+
+extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                                   const double *d_v, const double *d_a, const int32_t *d_col_idx, int n,
+                                   const double *d_tau, const double *h_block_weight, int nblocks, int64_t chunk_samples,
+                                   double *d_R_out) {
+    int rps = 0, ncols = 0;
+    if (int rc = figh_regressor_shape(model, mode, flags, &rps, &ncols)) return rc;
+    FIGH_REQUIRE(N >= 0 && chunk_samples >= 0, "negative size");
+    FIGH_REQUIRE(d_q && d_v && d_a && d_R_out, "NULL device pointer");
+    FIGH_REQUIRE(n >= 1 && (d_col_idx ? n <= ncols : n == ncols), "bad column count");
+    if (h_block_weight) FIGH_REQUIRE(nblocks > 0 && rps % nblocks == 0, "row-block weights must divide the rows of a sample");
+    if (int rc = ensure_device()) return rc;
+    const int nc = n + (d_tau ? 1 : 0);
+    if (N == 0) {
+        FIGH_HIP(hipMemsetAsync(d_R_out, 0, sizeof(double) * (size_t)nc * nc, stream()));
+        return FIGH_OK;
+    }
+    if (chunk_samples == 0) chunk_samples = default_chunk(rps, ncols);
+    const int64_t cs = chunk_samples < N ? chunk_samples : N;
+    const int64_t nchunks = (N + cs - 1) / cs;
+    double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs * ncols, 8));
+    double *tc = d_tau ? static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs, 10)) : nullptr;
+    double *stack = static_cast<double *>(workspace(sizeof(double) * (size_t)nchunks * nc * nc, 11));
+    if (!Wc || (d_tau && !tc) || !stack) return FIGH_ERR_ALLOC;
+    const int nq = model->host.nq, nv = model->host.nv;
+    int64_t k = 0;
+    for (int64_t lo = 0; lo < N; lo += cs, ++k) {
+        const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
+        if (int rc = figh_regressor_build(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv, d_a + lo * nv, Wc,
+                                          ncols, nullptr))
+            return rc;
+        if (d_tau)  // rows j*N + [lo, lo + nc_) of tau -> the chunk's joint-major vector (rows j*nc_ + i)
+            FIGH_HIP(hipMemcpy2DAsync(tc, sizeof(double) * nc_, d_tau + lo, sizeof(double) * N, sizeof(double) * nc_, rps,
+                                      hipMemcpyDeviceToDevice, stream()));
+        if (int rc = figh_tsqr(Wc, (int64_t)rps * nc_, ncols, d_col_idx, n, tc, h_block_weight, nblocks,
+                               stack + (size_t)k * nc * nc))
+            return rc;
+    }
+    return figh_tsqr_merge(stack, (int)nchunks, nc, d_R_out);
+}
+
+extern "C" int figh_regressor_gram(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                                   const double *d_v, const double *d_a, const int32_t *d_col_idx, int n,
+                                   const double *d_tau, int64_t chunk_samples, double *h_G, double *h_g,
+                                   double *h_tau_sq) {
+    FIGH_REQUIRE(h_G, "NULL output");
+    FIGH_REQUIRE(!d_tau || (h_g && h_tau_sq), "tau given but no output for W^T tau / tau^T tau");
+    const int nc = n + (d_tau ? 1 : 0);
+    FIGH_REQUIRE(n >= 1 && nc <= 384, "bad column count");
+    double *d_R = static_cast<double *>(workspace(sizeof(double) * (size_t)nc * nc, 12));
+    if (!d_R) return FIGH_ERR_ALLOC;
+    if (int rc = figh_regressor_tsqr(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_col_idx, n, d_tau, nullptr, 0,
+                                     chunk_samples, d_R))
+        return rc;
+    std::vector<double> R((size_t)nc * nc);
+    if (int rc = figh_memcpy_d2h(R.data(), d_R, sizeof(double) * R.size())) return rc;
+    // W^T W = R1^T R1, W^T tau = R1^T z, tau^T tau = z^T z + rho^2 with R = [R1 z; 0 rho]
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k <= i; ++k) s += R[(size_t)k * nc + i] * R[(size_t)k * nc + j];
+            h_G[(size_t)i * n + j] = s;
+            h_G[(size_t)j * n + i] = s;
+        }
+    if (d_tau) {
+        double tt = 0.0;
+        for (int k = 0; k < nc; ++k) tt += R[(size_t)k * nc + n] * R[(size_t)k * nc + n];
+        *h_tau_sq = tt;
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int k = 0; k <= i; ++k) s += R[(size_t)k * nc + i] * R[(size_t)k * nc + n];
+            h_g[i] = s;
+        }
+    }
+    return FIGH_OK;
+}

@@ -124,29 +124,24 @@ class IdentificationPipeline:
 
     # ------------------------------------------------------------------ one pass of the hot path
     def _run_chunked(self, strings):
+        """Memory-bounded pass through the streamed C-ABI entry points (W exists one chunk at a time, in a library
+        workspace): figh_regressor_colsq for the elimination, figh_regressor_tsqr for the triangle."""
         from .tools.regressor import regressor_flags
         ex, lib = self.exchange, _lib.load()
-        mode, flags, _ = regressor_flags(self.param, self.coupling)
-        rps, ncols = self.robot.device_model().shape(mode, flags)
-        chunks = self._chunks()
-        if self.W is None or self.W.rows != rps * self.chunk_samples:
-            self.W = GpuMatrix.empty(rps * self.chunk_samples, ncols)
+        mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+        dm = self.robot.device_model()
+        rps, ncols = dm.shape(mode, flags)
+        if getattr(self, "_d_colsq", None) is None or self._d_colsq.size != ncols:
             cap = ncols + 1
             self._d_colsq = _lib.DeviceArray((ncols,), np.float64)
             self._d_idx = _lib.DeviceArray((cap,), np.int32)
             self._d_Rm = _lib.DeviceArray((cap * cap,), np.float64)
             self._d_Rp = _lib.DeviceArray((cap * cap,), np.float64)
             self._d_R2 = _lib.DeviceArray((cap * cap,), np.float64)
-            self._d_stack = _lib.DeviceArray((len(chunks) * cap * cap,), np.float64)
-            self._d_tauc = _lib.DeviceArray((rps * self.chunk_samples,), np.float64)
-        W = self.W
-        # pass 1: column norms (W chunk written and discarded)
-        col_local = np.zeros(ncols)
-        for lo, hi in chunks:
-            self._build_chunk(lo, hi, W, self._d_colsq)
-            col_local += self._d_colsq.to_host()
-        d_tot = _lib.DeviceArray.from_host(col_local)
-        col_norm = ex.sum_columns(d_tot, ncols)
+        # pass 1: column norms
+        _lib.regressor_colsq(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._d_colsq,
+                             chunk_samples=self.chunk_samples)
+        col_norm = ex.sum_columns(self._d_colsq, ncols)
         idx_e = [i for i in range(ncols) if col_norm[i] < self.tol_e]
         kept = [i for i in range(ncols) if not col_norm[i] < self.tol_e]
         params_r = [self.names[i] for i in kept]
@@ -155,16 +150,10 @@ class IdentificationPipeline:
         nc = n + (1 if with_tau else 0)
         kept_i32 = np.asarray(kept, dtype=np.int32)
         _lib.check(lib.figh_memcpy_h2d(self._d_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
-        # pass 2: rebuild each chunk, factor it, stack the triangles
-        for k, (lo, hi) in enumerate(chunks):
-            self._build_chunk(lo, hi, W, None)
-            d_tc = None
-            if with_tau:
-                self._tau_chunk(lo, hi, rps, self._d_tauc)
-                d_tc = self._d_tauc
-            _lib.tsqr(W.buf, rps * (hi - lo), W.ld, self._d_idx, n, d_tc, None, _View(self._d_stack, k * nc * nc * 8))
+        # pass 2: every chunk rebuilt and factored, triangles merged
         d_R = self._d_Rm
-        _lib.tsqr_merge(self._d_stack, len(chunks), nc, d_R)
+        _lib.regressor_tsqr(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._d_idx, n,
+                            self.d_tau if with_tau else None, None, d_R, chunk_samples=self.chunk_samples)
         d_stack, count = ex.stack_triangles(d_R, nc)
         if count > 1:
             d_R = _lib.DeviceArray((nc * nc,), np.float64)

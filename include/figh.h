@@ -124,6 +124,29 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
 /* Sample-sharded reduction step: QR of `count` stacked nc x nc R factors (d_Rs: count*nc x nc) into one. */
 int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out);
 
+/* ------------------------------------------------------------------ streamed entry points (W never stored in full)
+ * The "fused" forms of SURVEY.md section 8b: the samples are processed in chunks of `chunk_samples` (0 = library
+ * default, about 2 GB of W); each chunk's W lives in a library workspace only until the next kernel has consumed it.
+ * Same mode / flags / ft_mask / q, v, a conventions as figh_regressor_build.  d_tau keeps the reference's layout
+ * (rows_per_sample * N entries, row j*N + i).
+ *
+ * figh_regressor_colsq: diag(W^T W) of the W that build_regressor_basic would return (regressor.py:243,271). */
+int figh_regressor_colsq(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                         const double *d_v, const double *d_a, int64_t chunk_samples, double *d_colsq);
+/* figh_regressor_tsqr: the R factor that figh_tsqr would return for that W (columns d_col_idx, optional tau column and
+ * per-row-block weights; nblocks must divide rows_per_sample, e.g. one weight per joint) -- qrdecomposition.py:105,
+ * 205,238,286 on top of regressor.py:20-227 without the 6N x ncols intermediate. */
+int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                        const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
+                        const double *h_block_weight, int nblocks, int64_t chunk_samples, double *d_R_out);
+/* figh_regressor_gram: h_G = W_e^T W_e (n x n, row-major, host), h_g = W_e^T tau (n), *h_tau_sq = tau^T tau, formed
+ * from the Householder R (G = R1^T R1): the normal-equation quantities of the SIP QP (identification_tools.py:528-531)
+ * and of the weighted LS statements (staubli_TX40/identification.py:320-327).  h_g / h_tau_sq may be NULL iff d_tau
+ * is NULL. */
+int figh_regressor_gram(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                        const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
+                        int64_t chunk_samples, double *h_G, double *h_g, double *h_tau_sq);
+
 /* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI), SURVEY.md section 8e
  * One process per GPU.  Rank 0 calls figh_comm_unique_id and ships the 128 bytes to the other ranks by any
  * means (the Python side uses the torch.distributed store); every rank then calls figh_comm_init. */

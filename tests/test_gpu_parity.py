@@ -446,3 +446,52 @@ def test_regressor_leading_dimension_and_colsq(lib, golden_ur10):
     assert np.abs(cs - d2.to_host()).max() <= 1e-13 * cs.max()
     with pytest.raises(_lib.FighError):
         _lib.regressor_build(robot.device_model(), mode, flags, ft, N, dq, dv, da, dW, 80, None)  # ldw < ncols
+
+
+# ------------------------------------------------------------------------------------------------ streamed C-ABI
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [0, 64, 150])
+def test_streamed_entry_points_equal_materialised(lib, golden, chunk):
+    """figh_regressor_colsq / figh_regressor_tsqr / figh_regressor_gram (W never stored in full, SURVEY 8b 'fused'
+    forms) against the same quantities of the materialised W: column norms, R^T R = W_e^T W_e, W_e^T tau, tau^T tau,
+    the rank decision and a joint-weighted variant."""
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.tools.regressor import regressor_flags
+    g = golden
+    q, v, a, tau = g["q_big"], g["v_big"], g["a_big"], g["tau"]
+    N = len(q)
+    W = _gpu_W(g, q, v, a)
+    robot = g.robot()
+    dm = robot.device_model()
+    mode, flags, ft = regressor_flags(g.param, g.coupling)
+    rps, ncols = dm.shape(mode, flags)
+    assert W.shape == (rps * N, ncols)
+    d_q, d_v, d_a = (_lib.DeviceArray.from_host(np.ascontiguousarray(x).reshape(-1)) for x in (q, v, a))
+    d_c = _lib.DeviceArray((ncols,))
+    _lib.regressor_colsq(dm, mode, flags, ft, N, d_q, d_v, d_a, d_c, chunk_samples=chunk)
+    ref_c = np.einsum("ij,ij->j", W, W)
+    assert np.abs(d_c.to_host() - ref_c).max() <= 1e-12 * ref_c.max()
+    keep = [i for i in range(ncols) if i not in set(g["idx_e"].tolist())]
+    n = len(keep)
+    d_idx = _lib.DeviceArray.from_host(np.asarray(keep, dtype=np.int32))
+    d_tau = _lib.DeviceArray.from_host(tau)
+    d_R = _lib.DeviceArray(((n + 1) * (n + 1),))
+    _lib.regressor_tsqr(dm, mode, flags, ft, N, d_q, d_v, d_a, d_idx, n, d_tau, None, d_R, chunk_samples=chunk)
+    R = np.triu(d_R.to_host().reshape(n + 1, n + 1))
+    We = W[:, keep]
+    A = np.c_[We, tau]
+    G = A.T @ A
+    assert np.abs(R.T @ R - G).max() <= 1e-11 * np.abs(G).max()
+    d = np.abs(np.diag(R))[:n]
+    assert [i for i in range(n) if d[i] > 1e-8] == list(g["idx_base"])
+    Gs, gs, tt = _lib.regressor_gram(dm, mode, flags, ft, N, d_q, d_v, d_a, d_idx, n, d_tau, chunk_samples=chunk)
+    assert np.abs(Gs - G[:n, :n]).max() <= 1e-11 * np.abs(G).max()
+    assert np.abs(gs - G[:n, n]).max() <= 1e-11 * np.abs(G[:n, n]).max()
+    assert abs(tt - G[n, n]) <= 1e-11 * G[n, n]
+    # one weight per row of a sample (joint / wrench component): QR of the row-scaled matrix
+    w = 0.5 + np.arange(rps) / rps
+    _lib.regressor_tsqr(dm, mode, flags, ft, N, d_q, d_v, d_a, d_idx, n, d_tau, w, d_R, chunk_samples=chunk)
+    Rw = np.triu(d_R.to_host().reshape(n + 1, n + 1))
+    Aw = A * np.repeat(w, N)[:, None]
+    Gw = Aw.T @ Aw
+    assert np.abs(Rw.T @ Rw - Gw).max() <= 1e-11 * np.abs(Gw).max()
