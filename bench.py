@@ -164,7 +164,8 @@ def main():
     except Exception:
         pass
     if "tsqr" in roof:
-        roof["tsqr"]["pipe"] = "fp64 VALU (v_fma_f64 + DPP/permlane); v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak"
+        roof["tsqr"]["pipe"] = ("fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand + permlane swaps); v_mfma_f64_16x16x4 has the "
+                              "same 78.6 TFLOP/s peak and does not overlap with fp64 VALU work (tools/microbench/latency.hip)")
         roof["tsqr"]["algorithmic_flops_per_sample"] = flops_per_sample
     if "regressor_chain" in roof:
         roof["regressor_chain"]["algorithmic_bytes_per_sample"] = bytes_per_sample
