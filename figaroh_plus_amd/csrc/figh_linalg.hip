@@ -86,7 +86,8 @@ template <int NCC, int NRC>
 struct Tsqr2State {
     static constexpr int RPL = 4 * NRC;  // rows per lane
     double T[NCC][RPL];
-    double *Rl;   // LDS triangle, row stride LDR
+    double *Rl;   // LDS triangle (packed, biased so that the compile-time row offsets apply)
+    double *red;  // LDS: 64 doubles of cross-row-group reduction scratch, private to the wave
     int lane_c;   // lane & 15
     int lane_g;   // lane >> 4
     int nc;
@@ -98,6 +99,21 @@ struct Tsqr2State {
 // rotation copies), the number of live chunks is known, and a step is straight-line code -- after the pivot chunk's
 // own dot product (the only input of the Householder scalars) the dot products of the trailing chunks and the LDS
 // reads of row k are independent of the rsq/rcp chain and are interleaved with it by the scheduler.
+// Sum over the four row groups through the wave's own 512 B of LDS: one ds_write_b64 + three ds_read_b64 + three
+// v_add_f64 instead of 4 v_mov + 4 v_permlane*_swap + 2 adds.  Every row group adds the same two pairs in the same
+// order: the result is bit-identical in all lanes.  Same-box A/B on the UR10 problem (3 repetitions each,
+// FIGH_TSQR_DBG=64 selects the swap version): 1.034 vs 1.080 ms -- the default for the 4-chunk level-0 kernel.
+__device__ __forceinline__ double allreduce_rowgroups_lds(double *red, const int lane, const double x) {
+    red[lane] = x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double a = red[lane ^ 16], b = red[lane ^ 32], c = red[lane ^ 48];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return (x + a) + (b + c);
+}
+
 // acc += (value of pv in lane-column K of my row group) * b as ONE instruction: gfx90a+ allow a DPP row_newbcast
 // operand on the DP ALU v_fmac_f64, so the pivot column is never materialised in registers (no v_mov_b64_dpp per
 // row, 32 VGPRs less).  The compiler does not form this instruction by itself.  Hazard: a VGPR written by a VALU
@@ -108,7 +124,13 @@ __device__ __forceinline__ void fmac_bcast(double &acc, const double pv, const d
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pv), "v"(b), "n"(K));
 }
 
-template <int KK, int P, int NCC, int NRC, bool TRI>
+template <bool LDSRED, int NCC, int NRC>
+__device__ __forceinline__ double tsqr2_reduce(Tsqr2State<NCC, NRC> &S, const double x) {
+    if constexpr (LDSRED) return allreduce_rowgroups_lds(S.red, 16 * S.lane_g + S.lane_c, x);
+    else return allreduce_rowgroups(x);
+}
+
+template <int KK, int P, int NCC, int NRC, bool TRI, bool LDSRED>
 __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
     constexpr int RPL = 4 * NRC;
     constexpr int LIVE = NCC - P;
@@ -128,7 +150,7 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
             fmac_bcast<KK>(s2, S.T[P][i + 2], S.T[P][i + 2]);
             fmac_bcast<KK>(s3, S.T[P][i + 3], S.T[P][i + 3]);
         }
-        d[0] = allreduce_rowgroups((s0 + s1) + (s2 + s3));
+        d[0] = tsqr2_reduce<LDSRED>(S, (s0 + s1) + (s2 + s3));
     }
     // row k of the triangle is requested before the dot product and pinned here, so that the LDS latency is not
     // part of the dependent chain below (the compiler would otherwise sink the read below the sigma branch)
@@ -159,7 +181,7 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
             fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
             fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
         }
-        d[cc] = allreduce_rowgroups(s0 + s1);
+        d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
     }
     // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
     //   - the pivot lane itself gets w = (alpha + sigma inv) tfac = alpha - beta, hence R_kk = alpha - w = beta and
@@ -180,20 +202,20 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
 // all column steps of panel P, then the next panel (compile-time recursion over the panels).  after(P) runs when
 // chunk P is retired (its registers are dead for the rest of the tile): the kernel requests the next tile's chunk P
 // into them there.
-template <int P, int NCC, int NRC, bool TRI, class AfterPanel>
+template <int P, int NCC, int NRC, bool TRI, bool LDSRED, class AfterPanel>
 __device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC> &S, const int first_nz, AfterPanel &&after) {
     if (16 * P + 15 >= first_nz) {
 #define FIGH_STEP(KK) \
-    if (16 * P + KK >= first_nz) tsqr2_step<KK, P, NCC, NRC, TRI>(S);
+    if (16 * P + KK >= first_nz) tsqr2_step<KK, P, NCC, NRC, TRI, LDSRED>(S);
         FIGH_STEP(0) FIGH_STEP(1) FIGH_STEP(2) FIGH_STEP(3) FIGH_STEP(4) FIGH_STEP(5) FIGH_STEP(6) FIGH_STEP(7)
         FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
 #undef FIGH_STEP
     }
     after(std::integral_constant<int, P>{});
-    if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, TRI>(S, first_nz, after);
+    if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, TRI, LDSRED>(S, first_nz, after);
 }
 
-template <int NCC, int NRC, bool TRI, bool PROF = false>
+template <int NCC, int NRC, bool TRI, bool PROF = false, bool LDSRED = false>
 __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
     const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
@@ -217,8 +239,12 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     // takes part in every step up to its last column, so the partially filled chunk must be the FIRST one -- for
     // nc = 50 the chunk holding 2 real columns is then live for 2 steps instead of 50 (-33 % chunk-steps on UR10).
     const int pad = 16 * NCC - nc;
+    // LDS: [64 doubles of reduction scratch][packed triangle without the rows of the padding columns]
+    int skip = 0;
+    for (int kp = 0; kp < pad; ++kp) skip += 16 * (NCC - (kp >> 4));
     Tsqr2State<NCC, NRC> S;
-    S.Rl = Rl;
+    S.red = Rl;
+    S.Rl = Rl + 64 - skip;
     S.lane_c = lane & 15;
     S.lane_g = lane >> 4;
     S.nc = nc;
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
         for (int i = 0; i < RPL; ++i) S.T[cc][i] = 0.0;
     {
         constexpr int tot = 256 * (NCC * NCC - (NCC * (NCC - 1)) / 2);
-        for (int e = lane; e < tot; e += 64) Rl[e] = 0.0;
+        for (int e = lane; e < 64 + tot - skip; e += 64) Rl[e] = 0.0;
     }
     __syncthreads();
 
@@ -270,20 +296,47 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     // halves of the grid therefore alternate their issue priority per tile, in antiphase, so that both waves of a
     // SIMD progress at a more even rate and the SIMD stays doubly occupied for longer (measured 1.120 -> 1.091 ms;
     // in the paired phase the SIMD is issue-bound, so this only shortens the single-wave tail).
-    int prio_phase = (dbg & 8) ? -1 : (wave >= tstep / 2 ? 1 : 0);
-    for (long t = wave; t < ntiles; t += tstep) {
-        if (prio_phase >= 0) {
-            if (prio_phase & 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
+    // (no ties: the younger half of the grid stays at priority 1, the older half alternates 2 / 0 per tile)
+    const bool younger = wave >= tstep / 2;
+    int prio_phase = 0;
+    if (!(dbg & 8) && younger) __builtin_amdgcn_s_setprio(1);
+    // Tile order: the wave's k-th tile is not tile wave + k*nwaves itself but its image under an 8-way interleave of
+    // the row range (position p -> tile (p mod 8) * ceil(ntiles/8) + p / 8).  In the joint-major row order whole
+    // row blocks are either compute-bound (rows of joint 1: all columns non-zero) or HBM-bound (rows of the last
+    // joints: a handful of column steps per 43 KB tile); with the plain order every wave walks through the blocks in
+    // lockstep and the kernel is a compute-bound phase followed by a bandwidth-bound phase.  Interleaved, each SIMD
+    // sees both kinds at any time and the two bounds overlap.
+    constexpr int GI = 8;
+    const long npg = (ntiles + GI - 1) / GI;
+    auto tile_at = [&](const long p) { return (dbg & 32) ? p : (p % GI) * npg + p / GI; };  // may be >= ntiles
+    long pos = wave;
+    while (pos < GI * npg && tile_at(pos) >= ntiles) pos += tstep;
+    while (pos < GI * npg) {
+        long posn = pos + tstep;
+        while (posn < GI * npg && tile_at(posn) >= ntiles) posn += tstep;
+        const long t = tile_at(pos);
+        const long tn = posn < GI * npg ? tile_at(posn) : ntiles;
+        pos = posn;
+        if (!(dbg & 8) && !younger) {
+            if (prio_phase & 1) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(2);
             ++prio_phase;
         }
-        const long r0 = t * M;
-        const long r0n = (t + tstep) * M;
+        long r0 = t * M;
+        long r0n = tn * M;
         const bool fast = r0 + M <= rend;
         const bool next_fast = r0n + M <= rend;
+        if (dbg & 16) {  // ablation: every tile re-reads one of the first 8 tiles of its sixth of the rows (L2-resident)
+            const long blk = rows / 6;
+            r0 = (r0 / blk) * blk + (r0 % blk) % (8 * M);
+            r0n = (r0n / blk) * blk + (r0n % blk) % (8 * M);
+        }
         const long long pc_a = PROF ? (long long)__builtin_readcyclecounter() : 0;
         if (fast) {
             if (!prefetched) load_head_chunks(r0);
+            // the last chunk (+ tau) is live until the end of the previous tile: requested here.  (Requesting it into
+            // a separate 16-double buffer during the last panel was measured: the load phase shrinks, the panels
+            // slow down by the same amount -- 256 VGPRs -- no net gain.)
             load_chunk(std::integral_constant<int, NCC - 1>{}, r0);
             if (tau_lane) {
 #pragma unroll
@@ -334,7 +387,7 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
         if (dbg & 1) first_nz = 16 * NCC + 16;
         const long long pc_b = PROF ? (long long)__builtin_readcyclecounter() : 0;
 
-        tsqr2_panels<0, NCC, NRC, TRI>(S, first_nz, [&](auto P) {
+        tsqr2_panels<0, NCC, NRC, TRI, LDSRED>(S, first_nz, [&](auto P) {
             if constexpr (decltype(P)::value < NCC - 1) {
                 if (next_fast) load_chunk(P, r0n);
             }
@@ -363,7 +416,7 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
         const int pk = kp >> 4;
         Rg[e] = (k >= nc || col < k)  // below the diagonal the LDS rows hold rounding residues, not results
                     ? 0.0
-                    : Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (kp & 15) * 16 * (NCC - pk) + (colp - 16 * pk)];
+                    : S.Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (kp & 15) * 16 * (NCC - pk) + (colp - 16 * pk)];
     }
 }
 
@@ -1132,6 +1185,14 @@ static const bool g_force_v2 = getenv("FIGH_TSQR_V3") == nullptr;
 static const bool g_pf = getenv("FIGH_TSQR_PF") != nullptr;
 static const int g_dbg = getenv("FIGH_TSQR_DBG") ? atoi(getenv("FIGH_TSQR_DBG")) : 0;
 
+// LDS of one tsqr2 wave: 64 doubles of reduction scratch + the packed triangle minus the rows of the padding columns
+static size_t tsqr2_lds_bytes(int ncc, int nc) {
+    const int pad = 16 * ncc - nc;
+    size_t skip = 0;
+    for (int kp = 0; kp < pad; ++kp) skip += 16 * (ncc - (kp >> 4));
+    return sizeof(double) * (64 + 256 * (size_t)(ncc * ncc - (ncc * (ncc - 1)) / 2) - skip);
+}
+
 // one TSQR level: rows of (W, ldw) -> nw triangles in Rws.  Returns nw (>0) or a negative status.
 static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
                        const double *d_blkw, long rows_per_blk, int nc, long target_waves, long align,
@@ -1162,7 +1223,7 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
         hipLaunchKernelGGL((tsqr3_kernel<5, false>), grid, block, sizeof(double) * nc * 80 + lds3_extra, stream(), W, rows,
                            ldw, col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg);
     } else if (nc <= 64 && !g_force_v1) {
-        const size_t lds2 = sizeof(double) * 256 * (4 * 4 - (4 * 3) / 2);  // packed triangle of all 4 panels
+        const size_t lds2 = tsqr2_lds_bytes(4, nc);
         if (tri)
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
                                d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
@@ -1199,11 +1260,14 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
                 fprintf(stderr, "\n[tsqr2 prof] ticks/wave quantiles: min %lld 10%% %lld 50%% %lld 90%% %lld 99%% %lld max %lld\n",
                         d[0], d[nw / 10], d[nw / 2], d[nw * 9 / 10], d[nw * 99 / 100], d[nw - 1]);
             }
-        } else
-            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
-                               d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
+        } else if (g_dbg & 64)  // A/B: permlane-swap reduction instead of the LDS one
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, false, false>), grid, block, lds2, stream(), W, rows, ldw,
+                               col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr);
+        else
+            hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, false, true>), grid, block, lds2, stream(), W, rows, ldw,
+                               col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr);
     } else if (nc <= 80 && !g_force_v1) {
-        const size_t lds2 = sizeof(double) * 256 * (5 * 5 - (5 * 4) / 2);
+        const size_t lds2 = tsqr2_lds_bytes(5, nc);
         hipLaunchKernelGGL((tsqr2_kernel<5, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
                            d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
@@ -1385,8 +1449,11 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     if (nc > 80 && !g_force_v1) target = cu_count();  // column-split workgroups of 8 waves: one per CU
     if (nc <= 80 && !g_force_v1) {  // register-tile kernel: as many waves per CU as its LDS triangle admits
         long per_cu = 4;  // tile + prefetched tile in registers: one wave per SIMD
-        if (nc <= 64 && g_force_v2) per_cu = 8;  // 256 registers, 20 KB LDS triangle: two waves per SIMD
-        else if (g_force_v2) per_cu = 5;          // 5 chunks: 30 KB LDS triangle per wave
+        if (g_force_v2) {  // 256 registers: two waves per SIMD when the LDS triangles allow it
+            per_cu = (long)((160 * 1024) / tsqr2_lds_bytes(nc <= 64 ? 4 : 5, nc));
+            if (per_cu > (nc <= 64 ? 8 : 4)) per_cu = nc <= 64 ? 8 : 4;
+            if (per_cu < 1) per_cu = 1;
+        }
         static const int g_wpc = getenv("FIGH_TSQR_WPC") ? atoi(getenv("FIGH_TSQR_WPC")) : 0;  // A/B: waves per CU
         if (g_wpc > 0) per_cu = g_wpc;
         target = cu_count() * per_cu;
