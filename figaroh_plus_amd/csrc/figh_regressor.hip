@@ -98,7 +98,12 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
     const long ntiles = (N + 63) / 64;
     const bool fric = flags & FIGH_FLAG_FRICTION, actin = flags & FIGH_FLAG_ACT_INERTIA, offs = flags & FIGH_FLAG_OFFSET;
 
-    double cs0 = 0.0, cs1 = 0.0;  // COLSQ: this thread owns columns lane and lane+64
+    // COLSQ: on joint row j the columns below 14 j are structurally zero, so the 64 lanes own columns 14 j + lane
+    // (csA[j]) and, where the row is wider than 64 live columns, 14 j + 64 + lane (csB[j]): 8 passes over the tile per
+    // 64 samples instead of 12.  The per-row owners are combined through LDS once per wave, rows in ascending order.
+    double csA[NJ], csB[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) csA[j] = csB[j] = 0.0;
 
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long i0 = t * 64;
@@ -158,8 +163,11 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             // ---- this lane's row (j, i): 14 columns per link
+            // links < j are structurally zero; columns below 14 (j - 1) are still zero from the previous row of this tile
+            if (j > 0) {
 #pragma unroll
-            for (int c = 0; c < 14 * j; ++c) my[c] = 0.0;
+                for (int c = 14 * (j - 1); c < 14 * j; ++c) my[c] = 0.0;
+            }
             double Jl[3] = {0, 0, 0}, Ja[3] = {P.axis[j][0], P.axis[j][1], P.axis[j][2]};
 #pragma unroll
             for (int k = j; k < NJ; ++k) {
@@ -216,7 +224,30 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
 
             // ---- stream the 64 x NC tile to W rows j*N+i0 .. (contiguous when ldw == NC)
             double *dst = W + ((long)j * N + i0) * ldw;
-            if (vec_ok) {
+            bool streamed = false;
+            if constexpr (G::VEC == 2) {
+                if (vec_ok && nvalid == 64 && ldw == NC) {
+                    // full tile, packed rows: the 64 rows are one contiguous run of 64 NC doubles in W.  Chunk id (16 B)
+                    // sits at byte 16 id in W and at 16 (id + r) in the padded tile, r = id / CH by a magic multiply
+                    // (exact for id < 64 CH <= 4096): 5 instructions per chunk instead of a division and two 64-bit
+                    // address computations.
+                    constexpr int CH = G::CH;
+                    constexpr unsigned MAGIC = ((1u << 20) + CH - 1) / CH;  // exact for id < 64 CH <= 3584 (checked, NJ <= 8)
+                    static_assert(64 * CH <= 4096, "magic division range");
+                    char *gbase = reinterpret_cast<char *>(dst) + 16 * lane;
+                    const char *tbase = reinterpret_cast<const char *>(tile);
+#pragma unroll
+                    for (int it = 0; it < CH; ++it) {
+                        const unsigned id = lane + 64u * it;
+                        const unsigned r = (id * MAGIC) >> 20;
+                        const double2 val = *reinterpret_cast<const double2 *>(tbase + 16u * (id + r));
+                        *reinterpret_cast<double2 *>(gbase + 1024 * it) = val;
+                    }
+                    streamed = true;
+                }
+            }
+            if (streamed) {
+            } else if (vec_ok) {
                 constexpr int CH = G::CH, VEC = G::VEC;
                 const int total = nvalid * CH;
                 for (int id = lane; id < total; id += 64) {
@@ -236,39 +267,40 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
                 }
             }
             if constexpr (COLSQ) {
-                // thread `lane` owns columns lane and lane+64: sum of squares down the tile (LDS reads pipelined)
+                const int lo = 14 * j, width = NC - lo;  // live columns of this row
                 if (nvalid == 64) {
-                    if (lane < NC) {
+                    if (lane < width) {
                         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
                         for (int r = 0; r < 64; r += 4) {
-                            const double x0 = tile[r * LDT + lane], x1 = tile[(r + 1) * LDT + lane];
-                            const double x2 = tile[(r + 2) * LDT + lane], x3 = tile[(r + 3) * LDT + lane];
+                            const double x0 = tile[r * LDT + lo + lane], x1 = tile[(r + 1) * LDT + lo + lane];
+                            const double x2 = tile[(r + 2) * LDT + lo + lane], x3 = tile[(r + 3) * LDT + lo + lane];
                             t0 += x0 * x0;
                             t1 += x1 * x1;
                             t2 += x2 * x2;
                             t3 += x3 * x3;
                         }
-                        cs0 += (t0 + t1) + (t2 + t3);
+                        csA[j] += (t0 + t1) + (t2 + t3);
                     }
-                    if (lane + 64 < NC) {
+                    if (width > 64 && lane + 64 < width) {
                         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
                         for (int r = 0; r < 64; r += 4) {
-                            const double x0 = tile[r * LDT + lane + 64], x1 = tile[(r + 1) * LDT + lane + 64];
-                            const double x2 = tile[(r + 2) * LDT + lane + 64], x3 = tile[(r + 3) * LDT + lane + 64];
+                            const double x0 = tile[r * LDT + lo + 64 + lane], x1 = tile[(r + 1) * LDT + lo + 64 + lane];
+                            const double x2 = tile[(r + 2) * LDT + lo + 64 + lane], x3 = tile[(r + 3) * LDT + lo + 64 + lane];
                             t0 += x0 * x0;
                             t1 += x1 * x1;
                             t2 += x2 * x2;
                             t3 += x3 * x3;
                         }
-                        cs1 += (t0 + t1) + (t2 + t3);
+                        csB[j] += (t0 + t1) + (t2 + t3);
                     }
                 } else {
-                    if (lane < NC)
-                        for (int r = 0; r < nvalid; ++r) cs0 += tile[r * LDT + lane] * tile[r * LDT + lane];
-                    if (lane + 64 < NC)
-                        for (int r = 0; r < nvalid; ++r) cs1 += tile[r * LDT + lane + 64] * tile[r * LDT + lane + 64];
+                    if (lane < width)
+                        for (int r = 0; r < nvalid; ++r) csA[j] += tile[r * LDT + lo + lane] * tile[r * LDT + lo + lane];
+                    if (lane + 64 < width)
+                        for (int r = 0; r < nvalid; ++r)
+                            csB[j] += tile[r * LDT + lo + 64 + lane] * tile[r * LDT + lo + 64 + lane];
                 }
             }
             __syncthreads();
@@ -276,8 +308,17 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
     }
     if constexpr (COLSQ) {
         static_assert(NC <= 128, "colsq ownership covers two columns per lane");
-        if (lane < NC) colsq_part[(long)blockIdx.x * NC + lane] = cs0;
-        if (lane + 64 < NC) colsq_part[(long)blockIdx.x * NC + lane + 64] = cs1;
+        __syncthreads();
+        for (int c = lane; c < NC; c += 64) tile[c] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int lo = 14 * j, width = NC - lo;
+            if (lane < width) tile[lo + lane] += csA[j];
+            if (lane + 64 < width) tile[lo + 64 + lane] += csB[j];
+            __syncthreads();
+        }
+        for (int c = lane; c < NC; c += 64) colsq_part[(long)blockIdx.x * NC + c] = tile[c];
     }
 }
 
