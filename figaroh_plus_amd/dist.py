@@ -93,7 +93,10 @@ class RcclExchange:
         return d_colsq.to_host()
 
     def stack_triangles(self, d_R, nc):
-        stack = self._lib.DeviceArray((self.world_size * nc * nc,), np.float64)
+        need = self.world_size * nc * nc
+        stack = getattr(self, "_stack", None)
+        if stack is None or stack.size < need:  # kept across steps: hipMalloc / hipFree synchronise the device
+            stack = self._stack = self._lib.DeviceArray((need,), np.float64)
         self._lib.check(self._lib.load().figh_comm_allgather(d_R.ptr, stack.ptr, nc * nc))
         return stack, self.world_size
 
