@@ -157,7 +157,7 @@ def main():
             pmc = json.load(f)
         if N == 1_000_000:
             for key, kname in (("regressor_chain", "regressor_chain_kernel<6, false, true>"),
-                               ("tsqr", "tsqr2_kernel<4, 4, false, false>")):
+                               ("tsqr", "tsqr2_kernel<4, 4, false, false, true>")):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
                     roof[key]["traffic_source"] = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
