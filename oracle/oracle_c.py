@@ -9,7 +9,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libfigh_oracle.so")
+# FIGH_ORACLE_ASAN=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so)) runs the tests against the
+# AddressSanitizer + UBSan build (`make -C oracle asan`): sanitizers are a CPU-build matter, the GPU pool has none.
+_ASAN = os.environ.get("FIGH_ORACLE_ASAN") == "1"
+_SO = os.path.join(_HERE, "libfigh_oracle_asan.so" if _ASAN else "libfigh_oracle.so")
 
 
 class _Model(C.Structure):
@@ -23,7 +26,7 @@ class _Model(C.Structure):
 def build(force=False):
     src = os.path.join(_HERE, "figh_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libfigh_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "asan" if _ASAN else "libfigh_oracle.so"])
     return _SO
 
 
