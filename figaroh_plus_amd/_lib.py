@@ -62,6 +62,9 @@ SIGNATURES = {
     "figh_regressor_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _c_double_p, _c_double_p,
                                       _c_double_p]),
+    "figh_filtfilt_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _c_double_p, _c_double_p,
+                                     C.c_int, C.c_int, _c_double_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                     C.POINTER(C.c_int64)]),
     "figh_comm_unique_id": (C.c_int, [C.c_void_p]),
     "figh_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "figh_comm_destroy": (C.c_int, []),
@@ -288,6 +291,18 @@ def regressor_gram(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_ta
                                      g.ctypes.data_as(_c_double_p) if g is not None else None,
                                      C.byref(tt) if d_tau is not None else None))
     return G, g, (tt.value if d_tau is not None else None)
+
+
+def filtfilt_cols(d_X, rows, cols, ldx, nblocks, form, b, a, zi, padlen, q, d_Y, ldy):
+    """Zero-phase filter + keep every q-th sample of every (row block, column) sequence; returns the output rows."""
+    b, a, zi = _f64(b), _f64(a), _f64(zi)
+    nsec = b.shape[0] if form == 0 else 1
+    order = 2 if form == 0 else b.size - 1
+    out = C.c_int64(0)
+    check(load().figh_filtfilt_cols(d_X.ptr, rows, cols, ldx, nblocks, form, b.ctypes.data_as(_c_double_p),
+                                    a.ctypes.data_as(_c_double_p), nsec, order, zi.ctypes.data_as(_c_double_p), padlen, q,
+                                    d_Y.ptr, ldy, C.byref(out)))
+    return out.value
 
 
 def tsqr_merge(d_Rs, count, nc, d_R):

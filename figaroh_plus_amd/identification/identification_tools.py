@@ -210,33 +210,82 @@ def calculate_first_second_order_differentiation(model, q, param, dt=None):
     return q[:-2], dq[:-1], ddq[:-1]
 
 
+def _filtfilt_device(x2d, nblocks, form, b, a, zi, padlen, q):
+    """Columns of x2d (rows x cols, made of nblocks row blocks) through figh_filtfilt_cols; returns (rows_out, cols)."""
+    x2d = np.ascontiguousarray(x2d, dtype=np.float64)
+    rows, cols = x2d.shape
+    d_x = _lib.DeviceArray.from_host(x2d.reshape(-1))
+    L = rows // nblocks
+    rows_out = ((L + q - 1) // q) * nblocks
+    d_y = _lib.DeviceArray((rows_out * cols,), np.float64)
+    got = _lib.filtfilt_cols(d_x, rows, cols, cols, nblocks, form, b, a, zi, padlen, q, d_y, cols)
+    assert got == rows_out
+    return d_y.to_host().reshape(rows_out, cols)
+
+
 def low_pass_filter_data(data, param, nbutter=5):
-    """Zero-phase Butterworth low-pass + border trimming -- identification_tools.py:390-424."""
+    """Zero-phase Butterworth low-pass + border trimming -- identification_tools.py:390-424.  The filter is designed
+    on the host (``signal.butter`` / ``lfilter_zi``: a dozen numbers); the forward-backward recursion over every column
+    runs on the device, operation by operation as ``signal.filtfilt(b, a, data, padtype='odd', padlen=...)``."""
     from scipy import signal
 
     cutoff = param["ts"] * param["cut_off_frequency_butterworth"] / 2
     b, a = signal.butter(nbutter, cutoff, "low")
     padlen = 3 * (max(len(b), len(a)) - 1)
-    data = signal.filtfilt(b, a, data, axis=0, padtype="odd", padlen=padlen)
+    data = np.asarray(data, dtype=np.float64)
+    x2d = data.reshape(data.shape[0], -1)
+    if x2d.shape[0] <= padlen:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % padlen)
+    b, a = b / a[0], a / a[0]
+    out = _filtfilt_device(x2d, 1, 1, b, a, signal.lfilter_zi(b, a), padlen, 1).reshape(data.shape)
     nbord = 5 * nbutter
-    return data[nbord:data.shape[0] - nbord]
+    return out[nbord:out.shape[0] - nbord]
+
+
+def _decimate_design(q, n=8):
+    """The IIR of ``scipy.signal.decimate(ftype='iir')``: Chebyshev-I order 8, 0.05 dB, 0.8/q, as second-order
+    sections, with SciPy's padlen rule for sosfiltfilt."""
+    from scipy import signal
+
+    sos = signal.cheby1(n, 0.05, 0.8 / q, output="sos")
+    ntaps = 2 * sos.shape[0] + 1
+    ntaps -= min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum())
+    return sos, signal.sosfilt_zi(sos), 3 * ntaps
 
 
 def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
     """Per-joint decimation of tau and of every column of W with ``scipy.signal.decimate(zero_phase=True)``
     (examples/staubli_TX40/identification.py:186-204, examples/tiago/identification.py:142-187).
-    Returns (list of W blocks, list of tau blocks).  Host SciPy for now ("next" row)."""
-    from scipy import signal
-
-    W = np.asarray(W)
+    Returns (list of W blocks, list of tau blocks).  Block i of W is ``W[i*nj:(i+1)*nj]`` with nj taken from tau, as in
+    the scripts (when tau is longer than W's joint blocks the W blocks are offset and the last one is shorter -- kept).
+    Every (block, column) sequence is one device thread running SciPy's sosfiltfilt recurrences (SURVEY 8f-1);
+    equal-length blocks share a launch."""
+    W = np.asarray(W, dtype=np.float64)
+    tau = np.asarray(tau, dtype=np.float64)
     nj = tau.shape[0] // nblocks
-    W_list, tau_list = [], []
-    for i in range(nblocks):
-        t = tau[i * nj:(i + 1) * nj]
-        blk = W[i * nj:i * nj + nj]
+    sos, zi, padlen = _decimate_design(q)
+
+    def run(x2d, nb):  # nb equal blocks stacked in x2d
         for _ in range(stages):
-            t = signal.decimate(t, q=q, zero_phase=True)
-            blk = signal.decimate(blk, q=q, zero_phase=True, axis=0)
-        W_list.append(np.ascontiguousarray(blk))
-        tau_list.append(t)
+            if x2d.shape[0] // nb <= padlen:
+                raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % padlen)
+            x2d = _filtfilt_device(x2d, nb, 0, sos[:, :3], sos[:, 3:], zi, padlen, q)
+        return x2d
+
+    t = run(tau[:nj * nblocks].reshape(-1, 1), nblocks)
+    lt = t.shape[0] // nblocks
+    tau_list = [np.ascontiguousarray(t[i * lt:(i + 1) * lt, 0]) for i in range(nblocks)]
+    lengths = [max(0, min(W.shape[0], (i + 1) * nj) - i * nj) for i in range(nblocks)]
+    W_list = [None] * nblocks
+    i = 0
+    while i < nblocks:  # consecutive blocks of equal length go through one launch
+        k = i
+        while k + 1 < nblocks and lengths[k + 1] == lengths[i]:
+            k += 1
+        nb = k - i + 1
+        y = run(W[i * nj:i * nj + nb * lengths[i]], nb)
+        ly = y.shape[0] // nb
+        for b in range(nb):
+            W_list[i + b] = np.ascontiguousarray(y[b * ly:(b + 1) * ly])
+        i = k + 1
     return W_list, tau_list

@@ -147,6 +147,20 @@ int figh_regressor_gram(figh_model_t model, int mode, int flags, int ft_mask, in
                         const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
                         int64_t chunk_samples, double *h_G, double *h_g, double *h_tau_sq);
 
+/* ------------------------------------------------------------------ zero-phase filtering / decimation
+ * The step on either side of the hot path on real data: scipy.signal.decimate(x, q, zero_phase=True) over every
+ * column of W_b and over tau, joint block by joint block (examples/staubli_TX40/identification.py:186-204,
+ * examples/tiago/identification.py:142-187), and signal.filtfilt of the joint positions (identification_tools.py:
+ * 390-424).  d_X is rows x cols (ldx), made of nblocks row blocks of rows/nblocks samples; every (block, column)
+ * sequence is filtered forward and backward with odd padding of `padlen` samples (SciPy's method='pad') and every
+ * q-th sample is kept: d_Y receives nblocks blocks of ceil(L/q) rows (*rows_out in total).
+ * form 0: second-order sections -- h_b / h_a are nsec x 3 (sos[:, :3] and sos[:, 3:]), order = 2, h_zi = sosfilt_zi
+ * (nsec x 2).  form 1: transfer function -- nsec = 1, h_b / h_a have order + 1 entries (a[0] = 1), h_zi = lfilter_zi.
+ * The recurrences follow SciPy's loops operation by operation (no FMA contraction). */
+int figh_filtfilt_cols(const double *d_X, int64_t rows, int cols, int64_t ldx, int nblocks, int form, const double *h_b,
+                       const double *h_a, int nsec, int order, const double *h_zi, int padlen, int q, double *d_Y,
+                       int64_t ldy, int64_t *rows_out);
+
 /* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI), SURVEY.md section 8e
  * One process per GPU.  Rank 0 calls figh_comm_unique_id and ships the 128 bytes to the other ranks by any
  * means (the Python side uses the torch.distributed store); every rank then calls figh_comm_init. */

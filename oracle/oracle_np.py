@@ -392,3 +392,35 @@ def weigthed_least_squares(nq, phi_b, W_b, tau_meas, tau_est, idx_tau_stop):
         p[ii * nb:(ii + 1) * nb] = 1.0 / sigma
         phi_b = np.linalg.pinv(W_b * p[:, None]) @ (p * tau_meas)
     return np.around(phi_b, 6)
+
+
+# ------------------------------------------------------------------------------------------------ preprocessing
+def low_pass_filter_data(data, param, nbutter=5):
+    """ORACLE: zero-phase Butterworth low-pass + border trimming (identification_tools.py:390-424), SciPy on the host."""
+    from scipy import signal
+
+    cutoff = param["ts"] * param["cut_off_frequency_butterworth"] / 2
+    b, a = signal.butter(nbutter, cutoff, "low")
+    padlen = 3 * (max(len(b), len(a)) - 1)
+    data = signal.filtfilt(b, a, data, axis=0, padtype="odd", padlen=padlen)
+    nbord = 5 * nbutter
+    return data[nbord:data.shape[0] - nbord]
+
+
+def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
+    """ORACLE: per-joint ``scipy.signal.decimate(zero_phase=True)`` of tau and of every column of W
+    (examples/staubli_TX40/identification.py:186-204, examples/tiago/identification.py:142-187)."""
+    from scipy import signal
+
+    W = np.asarray(W)
+    nj = tau.shape[0] // nblocks
+    W_list, tau_list = [], []
+    for i in range(nblocks):
+        t = tau[i * nj:(i + 1) * nj]
+        blk = W[i * nj:i * nj + nj]
+        for _ in range(stages):
+            t = signal.decimate(t, q=q, zero_phase=True)
+            blk = signal.decimate(blk, q=q, zero_phase=True, axis=0)
+        W_list.append(np.ascontiguousarray(blk))
+        tau_list.append(t)
+    return W_list, tau_list

@@ -360,23 +360,27 @@ def test_chunked_pipeline_equals_one_shot(lib, golden):
 
 
 def test_tx40_real_data_known_answers_hip(lib):
-    """Same known-answer replay with the HIP path: K1 on the 44 958 real samples, then (after the host-side
-    decimation, a 'next' row) elimination, double_QR, sigma, OLS and WLS through the kernels; compared with the
-    reference's committed TX40_bp_5.csv and with the reference-produced fixture."""
+    """Same known-answer replay with the HIP path end to end: Butterworth filtfilt of the joint positions on the
+    device, K1 on the 44 958 real samples, two decimate-by-10 stages of every column of W and of tau on the device,
+    then elimination, double_QR, sigma, OLS and WLS through the kernels; compared with the reference's committed
+    TX40_bp_5.csv and with the reference-produced fixture (the filtered trajectories bit for bit)."""
     from tx40_real_common import decimate_and_filter, load_fixture, trajectories, tx40
-    from figaroh_plus_amd.identification.identification_tools import (least_squares, relative_stdev,
+    from figaroh_plus_amd.identification.identification_tools import (decimate_joint_blocks, least_squares,
+                                                                       low_pass_filter_data, relative_stdev,
                                                                        weighted_least_squares_blocks)
     from figaroh_plus_amd.tools.qrdecomposition import double_QR
     from figaroh_plus_amd.tools.regressor import add_coupling_TX40, build_regressor_basic, eliminate_non_dynaffect
     z, meta = load_fixture()
     g, robot, param, params_std = tx40()
-    q, dq, ddq, tau = trajectories(z, robot, param)
+    q, dq, ddq, tau = trajectories(z, robot, param, low_pass_filter_data)
+    sel = z["row_sel"]
+    assert np.array_equal(q[sel], z["q_rows"]) and np.array_equal(dq[sel], z["dq_rows"])  # device filter == SciPy
     m = robot.model
     W = build_regressor_basic(robot, q, dq, ddq, param)
     W = add_coupling_TX40(W, m, robot.data, len(q), m.nq, m.nv, m.njoints, q, dq, ddq)
     chk = np.array([W.sum(), np.abs(W).sum(), (W * W).sum()])
     assert np.abs(chk - z["W_checksum"]).max() <= 1e-11 * np.abs(z["W_checksum"]).max()
-    W_, tau_, counts = decimate_and_filter(W, tau, param)
+    W_, tau_, counts = decimate_and_filter(W, tau, param, decimate_joint_blocks)
     assert counts == list(z["counts"])
     assert np.abs(W_[::97] - z["W_dec_rows"]).max() <= 1e-10 * np.abs(W_).max()
     W_e, params_r = eliminate_non_dynaffect(W_, params_std, 0.001)
@@ -495,3 +499,45 @@ def test_streamed_entry_points_equal_materialised(lib, golden, chunk):
     Aw = A * np.repeat(w, N)[:, None]
     Gw = Aw.T @ Aw
     assert np.abs(Rw.T @ Rw - Gw).max() <= 1e-11 * np.abs(Gw).max()
+
+
+# ------------------------------------------------------------------------------------------------ 8f-1 preprocessing
+@pytest.mark.parametrize("L,cols,nblocks,q", [(28, 1, 1, 10), (100, 3, 2, 10), (4496, 7, 6, 10), (1001, 5, 3, 4), (300, 2, 1, 1)])
+def test_decimate_matches_scipy(lib, L, cols, nblocks, q):
+    """figh_filtfilt_cols against scipy.signal.decimate(zero_phase=True) / sosfiltfilt, sequence by sequence: the
+    recurrences are SciPy's operation by operation, so the agreement is at rounding level (bit-equal in practice)."""
+    from scipy import signal
+    from figaroh_plus_amd.identification.identification_tools import _decimate_design, _filtfilt_device
+    rng = np.random.default_rng(L + cols)
+    t = np.arange(L * nblocks)[:, None]
+    x = np.sin(0.01 * t * (1 + np.arange(cols))) + 0.1 * rng.standard_normal((L * nblocks, cols)) + 3.0
+    sos, zi, padlen = _decimate_design(max(q, 2))
+    y = _filtfilt_device(x, nblocks, 0, sos[:, :3], sos[:, 3:], zi, padlen, q)
+    ref = np.vstack([signal.sosfiltfilt(sos, x[b * L:(b + 1) * L], axis=0)[::q] for b in range(nblocks)])
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max()
+    if q >= 2:
+        ref2 = np.vstack([signal.decimate(x[b * L:(b + 1) * L], q, zero_phase=True, axis=0) for b in range(nblocks)])
+        assert np.abs(y - ref2).max() <= 1e-13 * np.abs(ref2).max()
+
+
+def test_filtfilt_tf_matches_scipy_and_errors(lib):
+    from scipy import signal
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.identification.identification_tools import (_filtfilt_device, decimate_joint_blocks,
+                                                                       low_pass_filter_data)
+    rng = np.random.default_rng(3)
+    x = np.cumsum(rng.standard_normal((5000, 4)), axis=0)
+    param = {"ts": 0.0002, "cut_off_frequency_butterworth": 100.0}
+    for nb in (4, 5):
+        got = low_pass_filter_data(x, param, nb)
+        b, a = signal.butter(nb, param["ts"] * param["cut_off_frequency_butterworth"] / 2, "low")
+        ref = signal.filtfilt(b, a, x, axis=0, padtype="odd", padlen=3 * (max(len(b), len(a)) - 1))[5 * nb:-5 * nb]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    one = low_pass_filter_data(x[:, 0], param, 4)  # 1-D input like the reference's per-joint call
+    assert one.shape == (5000 - 40,)
+    with pytest.raises(ValueError):  # SciPy: "The length of the input vector x must be greater than padlen"
+        decimate_joint_blocks(np.ones((27 * 2, 3)), np.ones(27 * 2), 2)
+    with pytest.raises(_lib.FighError):
+        _filtfilt_device(np.ones((20, 1)), 1, 1, np.ones(3), np.ones(3), np.ones(2), 30, 1)

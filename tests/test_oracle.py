@@ -116,7 +116,7 @@ def test_tx40_real_data_known_answers(oracle_lib):
     from tx40_real_common import decimate_and_filter, load_fixture, trajectories, tx40
     z, meta = load_fixture()
     g, robot, param, params_std = tx40()
-    q, dq, ddq, tau = trajectories(z, robot, param)
+    q, dq, ddq, tau = trajectories(z, robot, param, oracle_np.low_pass_filter_data)
     sel = z["row_sel"]
     assert np.array_equal(q[sel], z["q_rows"]) and np.array_equal(dq[sel], z["dq_rows"])
     assert np.array_equal(ddq[sel], z["ddq_rows"])
@@ -126,7 +126,7 @@ def test_tx40_real_data_known_answers(oracle_lib):
     W = om.build_regressor_basic(q, dq, ddq, 0, 15)
     chk = np.array([W.sum(), np.abs(W).sum(), (W * W).sum()])
     assert np.abs(chk - z["W_checksum"]).max() <= 1e-11 * np.abs(z["W_checksum"]).max()
-    W_, tau_, counts = decimate_and_filter(W, tau, param)
+    W_, tau_, counts = decimate_and_filter(W, tau, param, oracle_np.decimate_joint_blocks)
     assert counts == list(z["counts"])
     assert np.abs(tau_ - z["tau_dec"]).max() <= 1e-12 * np.abs(tau_).max()
     assert np.abs(W_[::97] - z["W_dec_rows"]).max() <= 1e-10 * np.abs(W_).max()

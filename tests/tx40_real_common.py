@@ -15,10 +15,10 @@ def load_fixture():
     return z, meta
 
 
-def trajectories(z, robot, param):
-    """pos / curr measurements -> (q, dq, ddq, tau) exactly as the script prepares them."""
-    from figaroh_plus_amd.identification.identification_tools import (
-        calculate_first_second_order_differentiation, low_pass_filter_data)
+def trajectories(z, robot, param, low_pass_filter_data):
+    """pos / curr measurements -> (q, dq, ddq, tau) exactly as the script prepares them.  ``low_pass_filter_data``:
+    the oracle's (SciPy) or the product's (device) zero-phase filter."""
+    from figaroh_plus_amd.identification.identification_tools import calculate_first_second_order_differentiation
     pos, curr = z["pos_e9"] / 1e9, z["curr_e11"] / 1e11
     Nr = param["N"]
     red_q = np.diag(Nr[:6]).astype(float)
@@ -37,9 +37,8 @@ def trajectories(z, robot, param):
     return q, dq, ddq, np.asarray(tau_T).ravel()
 
 
-def decimate_and_filter(W, tau, param):
+def decimate_and_filter(W, tau, param, decimate_joint_blocks):
     """two decimate-by-10 stages per joint block, then drop the rows where |fv_i column| < dq_lim_def[i]"""
-    from figaroh_plus_amd.identification.identification_tools import decimate_joint_blocks
     nj = tau.shape[0] // 6
     W_list, tau_list = decimate_joint_blocks(W[:6 * nj], tau, 6, q=10, stages=2)
     counts = []
