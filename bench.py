@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1_000_000, help="samples per GPU")
-    ap.add_argument("--cpu-samples", type=int, default=30000)
+    ap.add_argument("--cpu-samples", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
     args = ap.parse_args()
