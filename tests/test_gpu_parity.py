@@ -541,3 +541,23 @@ def test_filtfilt_tf_matches_scipy_and_errors(lib):
         decimate_joint_blocks(np.ones((27 * 2, 3)), np.ones(27 * 2), 2)
     with pytest.raises(_lib.FighError):
         _filtfilt_device(np.ones((20, 1)), 1, 1, np.ones(3), np.ones(3), np.ones(2), 30, 1)
+
+
+# ------------------------------------------------------------------------------------------------ 8f-2 objective
+def test_excitation_objective_matches_numpy_cond(lib, golden):
+    """cond(W_b) of examples/tiago/optimal_trajectory.py:100-133 without storing W: streamed triangle, optional stack."""
+    from figaroh_plus_amd.tools.excitation import base_regressor_triangle, objective_cond
+    g = golden
+    q, v, a = g["q_big"], g["v_big"], g["a_big"]
+    W = _gpu_W(g, q, v, a)
+    keep = [i for i in range(W.shape[1]) if i not in set(g["idx_e"].tolist())]
+    Wb = W[:, keep][:, g["idx_base"]]
+    ref = np.linalg.cond(Wb)
+    got = objective_cond(g.robot(), q, v, a, g.param, g["idx_e"], g["idx_base"], coupling=g.coupling)
+    assert abs(got - ref) <= 1e-9 * ref
+    # second trajectory stacked under the first: cond(vstack) from the merged triangles
+    h = len(q) // 2
+    R1 = base_regressor_triangle(g.robot(), q[:h], v[:h], a[:h], g.param, g["idx_e"], g["idx_base"], coupling=g.coupling)
+    got2 = objective_cond(g.robot(), q[h:], v[h:], a[h:], g.param, g["idx_e"], g["idx_base"], R_stack=R1,
+                          coupling=g.coupling)
+    assert abs(got2 - ref) <= 1e-9 * ref  # same rows as the one-shot matrix, stacked in two pieces
