@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// tsqr_wide_kernel<CPW>: 80 < n <= 384 columns (TIAGo 241, TALOS 331, human 191).  The tile is too wide for one
+// tsqr_wide_kernel<CPW>: 80 < n <= 512 columns (TIAGo 241, TALOS 331, human 191; 400 for the human SIP program).  The tile is too wide for one
 // wave, so a workgroup of 8 waves splits the COLUMNS of the same 64 rows: wave w owns the 16-column chunks
 // w, w+8, w+16 (CPW per wave) in the C-layout registers of tsqr2.  Per column step the owner of the pivot chunk
 // broadcasts the pivot column (64 doubles) and alpha through LDS (ping-pong buffers: one barrier per step), every
@@ -1271,19 +1271,22 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
         hipLaunchKernelGGL((tsqr2_kernel<5, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
                            d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
-    else if (nc <= 384 && !g_force_v1) {
+    else if (nc <= 512 && !g_force_v1) {
         // column-split workgroups: nw here counts workgroups (one private triangle each)
         if (nc <= 256)
             hipLaunchKernelGGL((tsqr_wide_kernel<2>), grid, dim3(512), 0, stream(), W, rows, ldw, col_idx, n, tau, d_blkw,
                                rows_per_blk, Rws_out, nc);
-        else
+        else if (nc <= 384)
             hipLaunchKernelGGL((tsqr_wide_kernel<3>), grid, dim3(512), 0, stream(), W, rows, ldw, col_idx, n, tau, d_blkw,
+                               rows_per_blk, Rws_out, nc);
+        else  // the human model's 400 inertial columns (SIP quadratic program)
+            hipLaunchKernelGGL((tsqr_wide_kernel<4>), grid, dim3(512), 0, stream(), W, rows, ldw, col_idx, n, tau, d_blkw,
                                rows_per_blk, Rws_out, nc);
     } else if (nc <= 128) FIGH_TSQR_LAUNCH(2, 32, false);
     else if (nc <= 256) FIGH_TSQR_LAUNCH(4, 16, false);
     else if (nc <= 384) FIGH_TSQR_LAUNCH(6, 16, false);
     else {
-        set_error("figh_tsqr: more than 384 columns not supported yet");
+        set_error("figh_tsqr: more than 512 columns not supported yet");
         return FIGH_ERR_UNSUPPORTED;
     }
 #undef FIGH_TSQR_LAUNCH
@@ -1430,7 +1433,7 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     FIGH_REQUIRE(d_W && d_R_out, "NULL device pointer");
     FIGH_REQUIRE(rows > 0 && n > 0 && ldw > 0, "bad shape");
     const int nc = n + (d_tau ? 1 : 0);
-    FIGH_REQUIRE(nc <= 384, "figh_tsqr: more than 384 columns not supported yet");
+    FIGH_REQUIRE(nc <= 512, "figh_tsqr: more than 512 columns not supported yet");
     FIGH_REQUIRE(ldw < (1L << 24), "figh_tsqr: leading dimension must be below 2^24 elements");
     if (int rc = ensure_device()) return rc;
     const double *d_blkw = nullptr;
@@ -1490,7 +1493,7 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
 
 int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out) {
     FIGH_REQUIRE(d_Rs && d_R_out, "NULL device pointer");
-    FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 384, "bad shape");
+    FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 512, "bad shape");
     if (int rc = ensure_device()) return rc;
     if (count == 1) {
         FIGH_HIP(hipMemcpyAsync(d_R_out, d_Rs, sizeof(double) * (size_t)nc * nc, hipMemcpyDeviceToDevice, stream()));

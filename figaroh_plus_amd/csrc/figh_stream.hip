@@ -105,7 +105,7 @@ extern "C" int figh_regressor_gram(figh_model_t model, int mode, int flags, int 
     FIGH_REQUIRE(h_G, "NULL output");
     FIGH_REQUIRE(!d_tau || (h_g && h_tau_sq), "tau given but no output for W^T tau / tau^T tau");
     const int nc = n + (d_tau ? 1 : 0);
-    FIGH_REQUIRE(n >= 1 && nc <= 384, "bad column count");
+    FIGH_REQUIRE(n >= 1 && nc <= 512, "bad column count");
     double *d_R = static_cast<double *>(workspace(sizeof(double) * (size_t)nc * nc, 12));
     if (!d_R) return FIGH_ERR_ALLOC;
     if (int rc = figh_regressor_tsqr(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_col_idx, n, d_tau, nullptr, 0,

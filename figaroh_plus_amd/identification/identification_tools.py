@@ -289,3 +289,31 @@ def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
             W_list[i + b] = np.ascontiguousarray(y[b * ly:(b + 1) * ly])
         i = k + 1
     return W_list, tau_list
+
+
+def sip_qp_terms(robot, q, v, a, tau, param, col_idx, phi_ref, alpha, coupling=False):
+    """The data terms of ``calculate_standard_parameters`` (identification_tools.py:466-572, the SIP quadratic
+    program): ``P = (1-alpha) sf1 I + alpha sf2 W^T W`` and ``r = -((1-alpha) sf1 phi_ref + alpha sf2 W^T tau)`` with
+    ``sf1 = 1 / (max(phi_ref) len(phi_ref))``, ``sf2 = 1 / (max(tau) len(tau))`` (``:528-531``), for the columns
+    ``col_idx`` of the regressor of the samples (q, v, a).  W^T W and W^T tau come from ``figh_regressor_gram`` (formed
+    from the Householder triangle, W never stored); the constraint matrices G, h and the QP solve (quadprog) stay with
+    the caller.  Returns (P, r)."""
+    from ..tools.regressor import _samples_to_device, regressor_flags
+
+    mode, flags, ft_mask = regressor_flags(param, coupling)
+    dm = robot.device_model()
+    cols = np.ascontiguousarray(col_idx, dtype=np.int32)
+    n = len(cols)
+    phi_ref = np.asarray(phi_ref, dtype=np.float64)
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    if phi_ref.shape != (n,):
+        raise ValueError("phi_ref must have one entry per selected column")
+    N, d_q, d_v, d_a = _samples_to_device(robot.model, q, v, a)
+    d_idx = _lib.DeviceArray.from_host(cols)
+    d_tau = _lib.DeviceArray.from_host(tau)
+    G, g, _ = _lib.regressor_gram(dm, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau)
+    sf1 = 1 / (np.max(phi_ref) * len(phi_ref))
+    sf2 = 1 / (np.max(tau) * len(tau))
+    P = (1 - alpha) * sf1 * np.eye(n) + alpha * sf2 * G
+    r = -((1 - alpha) * sf1 * phi_ref + sf2 * alpha * g)
+    return P, r

@@ -402,7 +402,7 @@ def test_tx40_real_data_known_answers_hip(lib):
     assert (np.abs(std_w - z["std_wls"])[ok] / z["std_wls"][ok]).max() <= 2e-3
 
 
-@pytest.mark.parametrize("n", [1, 15, 16, 17, 49, 63, 64, 65, 79, 80, 81, 128, 200, 257])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 49, 63, 64, 65, 79, 80, 81, 128, 200, 257, 384, 400, 511])
 @pytest.mark.parametrize("rows", [1, 63, 64, 65, 1000, 20011])
 def test_tsqr_shapes_against_lapack(lib, n, rows):
     """Every kernel family / boundary of figh_tsqr (1 wave, tsqr2 4 and 5 chunks, column-split workgroups) on
@@ -561,3 +561,25 @@ def test_excitation_objective_matches_numpy_cond(lib, golden):
     got2 = objective_cond(g.robot(), q[h:], v[h:], a[h:], g.param, g["idx_e"], g["idx_base"], R_stack=R1,
                           coupling=g.coupling)
     assert abs(got2 - ref) <= 1e-9 * ref  # same rows as the one-shot matrix, stacked in two pieces
+
+
+# ------------------------------------------------------------------------------------------------ 8f-3 SIP QP terms
+def test_sip_qp_terms_match_reference_formulas(lib, golden):
+    """P and r of calculate_standard_parameters (identification_tools.py:528-531) against the same NumPy statements on
+    the materialised W (inertial columns only, as the human example passes them)."""
+    from figaroh_plus_amd.identification.identification_tools import sip_qp_terms
+    g = golden
+    q, v, a, tau = g["q_big"], g["v_big"], g["a_big"], g["tau"]
+    W = _gpu_W(g, q, v, a)
+    nl = (W.shape[1] - (3 if g.coupling else 0)) // 14
+    cols = [14 * k + s for k in range(nl) for s in range(10)]
+    phi_ref = np.linspace(0.5, 2.0, len(cols))
+    alpha = 0.8
+    P, r = sip_qp_terms(g.robot(), q, v, a, tau, g.param, cols, phi_ref, alpha, coupling=g.coupling)
+    Wc = W[:, cols]
+    sf1 = 1 / (np.max(phi_ref) * len(phi_ref))
+    sf2 = 1 / (np.max(tau) * len(tau))
+    P_ref = (1 - alpha) * sf1 * np.eye(Wc.shape[1]) + alpha * sf2 * np.matmul(Wc.T, Wc)
+    r_ref = -((1 - alpha) * sf1 * phi_ref.T + sf2 * alpha * np.matmul(tau.T, Wc))
+    assert np.abs(P - P_ref).max() <= 1e-11 * np.abs(P_ref).max()
+    assert np.abs(r - r_ref).max() <= 1e-11 * np.abs(r_ref).max()
