@@ -515,6 +515,7 @@ __global__ __launch_bounds__(512) void tsqr_wide_kernel(const double *__restrict
                                                         const long rows_per_blk, double *__restrict__ Rws, const int nc) {
     constexpr int NW = 8;
     __shared__ double xl[2][80];
+    __shared__ int fnz[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lane_c = lane & 15, lane_g = lane >> 4;
     const int nchunks = (nc + 15) >> 4;
@@ -558,15 +559,35 @@ __global__ __launch_bounds__(512) void tsqr_wide_kernel(const double *__restrict
                 const double v = src[s][rowc * stride[s]];
                 T[s][i] = (inb && live[s]) ? v * scale : 0.0;
             }
+        // first column with a non-zero in this tile (all 8 waves): the steps before it are identities.  Stacked
+        // triangles (merge levels) and the joint-torque rows of a tree (row block j only touches the links of its
+        // subtree) start far to the right.
+        int myfirst = nc;
+#pragma unroll
+        for (int s = CPW - 1; s >= 0; --s) {
+            bool nz = false;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nz |= (T[s][i] != 0.0);
+            const unsigned long long b = __ballot(nz);
+            const unsigned m16 = (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);
+            if (m16) myfirst = 16 * (wave + NW * s) + __ffs((int)m16) - 1;
+        }
+        if (lane == 0) fnz[wave] = myfirst;
+        __syncthreads();
+        int first_nz = fnz[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) first_nz = min(first_nz, fnz[w]);
+        first_nz = __builtin_amdgcn_readfirstlane(first_nz);
         double Rk[CPW], Rn[CPW];
 #pragma unroll
         for (int s = 0; s < CPW; ++s) {
             const int col = 16 * (wave + NW * s) + lane_c;
-            Rk[s] = (col < nc && wave + NW * s < nchunks) ? Rg[col] : 0.0;  // row 0
+            Rk[s] = (first_nz < nc && col < nc && wave + NW * s < nchunks) ? Rg[(long)first_nz * nc + col] : 0.0;
         }
-        for (int p = 0; p < nchunks; ++p) {
+        for (int p = first_nz >> 4; p < nchunks; ++p) {
 #define FIGH_WSTEP(KK) \
-    if (16 * p + KK < nc) tsqr_wide_step<KK, CPW>(T, p, nchunks, nc, lane_c, lane_g, wave, xl, Rg, Rk, Rn);
+    if (16 * p + KK >= first_nz && 16 * p + KK < nc) \
+        tsqr_wide_step<KK, CPW>(T, p, nchunks, nc, lane_c, lane_g, wave, xl, Rg, Rk, Rn);
             FIGH_WSTEP(0) FIGH_WSTEP(1) FIGH_WSTEP(2) FIGH_WSTEP(3) FIGH_WSTEP(4) FIGH_WSTEP(5) FIGH_WSTEP(6)
             FIGH_WSTEP(7) FIGH_WSTEP(8) FIGH_WSTEP(9) FIGH_WSTEP(10) FIGH_WSTEP(11) FIGH_WSTEP(12) FIGH_WSTEP(13)
             FIGH_WSTEP(14) FIGH_WSTEP(15)
