@@ -54,6 +54,16 @@ struct ProfileScope {
 // scratch buffer owned by the library, grown on demand (device)
 void *workspace(size_t bytes, int slot);
 
+}  // namespace figh
+
+// internal (not part of include/figh.h): level 0 of the TSQR only, see figh_linalg.hip
+extern "C" int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
+                                const double *d_tau, const double *h_block_weight, int nblocks, double *d_tri_out,
+                                int64_t capacity, int64_t *count_out, double **ws_out, int *padded_out);
+extern "C" int64_t figh_tsqr_level0_capacity(int nc);
+
+namespace figh {
+
 #define FIGH_HIP(expr)                                                                          \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \

@@ -1449,9 +1449,14 @@ int figh_block_sqnorm(const double *d_a, const double *d_b, int64_t rows, int nb
     return FIGH_OK;
 }
 
-int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
-              const double *h_block_weight, int nblocks, double *d_R_out) {
-    FIGH_REQUIRE(d_W && d_R_out, "NULL device pointer");
+// Level 0 only (internal, figh_internal.h): the per-wave / per-workgroup triangles of W go to d_tri_out (compact
+// nc x nc each, at most `capacity` of them, *count_out written) -- or, with d_tri_out == nullptr, to the library
+// workspace whose address is returned in *ws_out.  The streamed entry points stack the triangles of all their sample
+// chunks this way and run the merge tree once.
+int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
+                     const double *h_block_weight, int nblocks, double *d_tri_out, int64_t capacity, int64_t *count_out,
+                     double **ws_out, int *padded_out) {
+    FIGH_REQUIRE(d_W && count_out, "NULL device pointer");
     FIGH_REQUIRE(rows > 0 && n > 0 && ldw > 0, "bad shape");
     const int nc = n + (d_tau ? 1 : 0);
     FIGH_REQUIRE(nc <= 512, "figh_tsqr: more than 512 columns not supported yet");
@@ -1493,11 +1498,16 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     // level-0 triangles in the zero-padded TRI merge format: measured SLOWER (reduce level 0.208 vs 0.167 ms: 28 %
     // more tiles outweigh the skipped row chunks), so it stays an A/B option (FIGH_TSQR_TRI)
     static const bool g_tri = getenv("FIGH_TSQR_TRI") != nullptr;
-    const bool padded = g_tri && nc <= 64 && !g_force_v1 && g_force_v2;
+    const bool padded = g_tri && nc <= 64 && !g_force_v1 && g_force_v2 && d_tri_out == nullptr;
     const int out_rows = padded ? 64 : nc;
     long nw_est = target + 1;
-    double *Rws = static_cast<double *>(workspace(sizeof(double) * (size_t)out_rows * nc * nw_est, 5));
-    if (!Rws) return FIGH_ERR_ALLOC;
+    double *Rws = d_tri_out;
+    if (Rws) {
+        FIGH_REQUIRE(capacity >= nw_est, "figh_tsqr_level0: triangle buffer too small");
+    } else {
+        Rws = static_cast<double *>(workspace(sizeof(double) * (size_t)out_rows * nc * nw_est, 5));
+        if (!Rws) return FIGH_ERR_ALLOC;
+    }
     long nw = 0;
     {
         ProfileScope scope(rows >= 65536 ? "tsqr" : "tsqr_small");
@@ -1505,12 +1515,36 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
                                 out_rows))
             return rc;
     }
+    (void)tri;
+    *count_out = nw;
+    if (ws_out) *ws_out = Rws;
+    if (padded_out) *padded_out = padded ? 1 : 0;
+    return FIGH_OK;
+}
+
+// upper bound of the triangles one figh_tsqr_level0 call can produce (for sizing the stack of a streamed run)
+int64_t figh_tsqr_level0_capacity(int nc) {
+    const long per_cu = (nc > 80 && !g_force_v1) ? 1 : 8;  // column-split workgroups: one triangle per CU
+    return (int64_t)cu_count() * per_cu + 1;
+}
+
+int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
+              const double *h_block_weight, int nblocks, double *d_R_out) {
+    FIGH_REQUIRE(d_W && d_R_out, "NULL device pointer");
+    int64_t nw = 0;
+    double *Rws = nullptr;
+    int padded = 0;
+    if (int rc = figh_tsqr_level0(d_W, rows, ldw, d_col_idx, n, d_tau, h_block_weight, nblocks, nullptr, 0, &nw, &Rws,
+                                  &padded))
+        return rc;
+    const int nc = n + (d_tau ? 1 : 0);
     if (nw == 1) {
-        FIGH_HIP(hipMemcpyAsync(d_R_out, Rws, tri, hipMemcpyDeviceToDevice, stream()));
+        FIGH_HIP(hipMemcpyAsync(d_R_out, Rws, sizeof(double) * (size_t)nc * nc, hipMemcpyDeviceToDevice, stream()));
         return FIGH_OK;
     }
-    return tsqr_reduce(Rws, nw, nc, d_R_out, padded);
+    return tsqr_reduce(Rws, nw, nc, d_R_out, padded != 0);
 }
+
 
 int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out) {
     FIGH_REQUIRE(d_Rs && d_R_out, "NULL device pointer");

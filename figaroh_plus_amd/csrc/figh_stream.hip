@@ -79,11 +79,14 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     const int64_t nchunks = (N + cs - 1) / cs;
     double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs * ncols, 8));
     double *tc = d_tau ? static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs, 10)) : nullptr;
-    double *stack = static_cast<double *>(workspace(sizeof(double) * (size_t)nchunks * nc * nc, 11));
+    // level-0 triangles of ALL chunks are stacked and the merge tree runs once (a merge is latency-bound: running it
+    // per chunk cost 158 ms of the 1.24 s human pass)
+    const int64_t per_chunk = figh_tsqr_level0_capacity(nc);
+    double *stack = static_cast<double *>(workspace(sizeof(double) * (size_t)nchunks * per_chunk * nc * nc, 11));
     if (!Wc || (d_tau && !tc) || !stack) return FIGH_ERR_ALLOC;
     const int nq = model->host.nq, nv = model->host.nv;
-    int64_t k = 0;
-    for (int64_t lo = 0; lo < N; lo += cs, ++k) {
+    int64_t have = 0;
+    for (int64_t lo = 0; lo < N; lo += cs) {
         const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
         if (int rc = figh_regressor_build(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv, d_a + lo * nv, Wc,
                                           ncols, nullptr))
@@ -91,11 +94,14 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
         if (d_tau)  // rows j*N + [lo, lo + nc_) of tau -> the chunk's joint-major vector (rows j*nc_ + i)
             FIGH_HIP(hipMemcpy2DAsync(tc, sizeof(double) * nc_, d_tau + lo, sizeof(double) * N, sizeof(double) * nc_, rps,
                                       hipMemcpyDeviceToDevice, stream()));
-        if (int rc = figh_tsqr(Wc, (int64_t)rps * nc_, ncols, d_col_idx, n, tc, h_block_weight, nblocks,
-                               stack + (size_t)k * nc * nc))
+        int64_t got = 0;
+        if (int rc = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ncols, d_col_idx, n, tc, h_block_weight, nblocks,
+                                      stack + (size_t)have * nc * nc, per_chunk, &got, nullptr, nullptr))
             return rc;
+        have += got;
     }
-    return figh_tsqr_merge(stack, (int)nchunks, nc, d_R_out);
+    FIGH_REQUIRE(have < (1LL << 31), "too many level-0 triangles");
+    return figh_tsqr_merge(stack, (int)have, nc, d_R_out);
 }
 
 extern "C" int figh_regressor_gram(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
