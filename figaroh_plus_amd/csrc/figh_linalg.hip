@@ -431,57 +431,73 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
 template <int KK, int CPW>
 __device__ __forceinline__ void tsqr_wide_step(double (&T)[CPW][16], const int p, const int nchunks, const int nc,
                                                const int lane_c, const int lane_g, const int wave,
-                                               double (*xl)[80], double *__restrict__ Rg, double (&Rk)[CPW],
-                                               double (&Rn)[CPW]) {
+                                               double (*xl)[80], double *__restrict__ red,
+                                               double *__restrict__ Rg, double (&Rk)[CPW], double (&Rn)[CPW]) {
     constexpr int NW = 8;
     const int k = 16 * p + KK;
     const int buf = k & 1;
     const int wo = p & (NW - 1), so = p >> 3;  // owner wave and its slot of the pivot chunk
+    // The owner of the pivot chunk publishes, through LDS, the pivot column (row group g's 16 values contiguous:
+    // xl[buf][16 g + 4 rc + r]) AND the Householder scalars inv = 1/(alpha - beta), tfac = tau -- it has x and alpha
+    // in registers anyway, and the other seven waves then skip sigma = x^T x (16 FMAs + a cross-row reduction) and
+    // the 18-operation rsq/rcp chain.  The kernel is issue-bound at two waves per SIMD, so the instructions saved in
+    // the non-owners are time saved; the critical path (chain before the barrier instead of after it) is unchanged.
     if (wave == wo) {
         double xo[16];
+        double a0 = 0.0;
 #pragma unroll
         for (int s = 0; s < CPW; ++s)
             if (s == so) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) xo[i] = row_bcast<KK>(T[s][i]);
-                const double a0 = row_bcast<KK>(Rk[s]);
-                if (lane_c == 0 && lane_g == 0) xl[buf][64] = a0;
+                a0 = row_bcast<KK>(Rk[s]);
             }
+        double ss0 = 0.0, ss1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            ss0 = fma(xo[i], xo[i], ss0);
+            ss1 = fma(xo[i + 1], xo[i + 1], ss1);
+        }
+        const double sigma = allreduce_rowgroups(ss0 + ss1);
+        double inv = 0.0, tfac = 0.0;  // sigma == 0: H = I
+        if (uniform_of(sigma) != 0.0) {
+            const double q2 = fma(a0, a0, sigma);
+            const double hq = -0.5 * q2;
+            double rs = __builtin_amdgcn_rsq(q2);
+            rs = rs * fma(hq * rs, rs, 1.5);
+            rs = rs * fma(hq * rs, rs, 1.5);
+            const double dsum = fma(q2, rs, fabs(a0));
+            double ri = __builtin_amdgcn_rcp(dsum);
+            ri = ri * fma(-dsum, ri, 2.0);
+            ri = ri * fma(-dsum, ri, 2.0);
+            inv = copysign(ri, a0);
+            tfac = dsum * rs;
+        }
         if (lane_c == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) xl[buf][16 * (i >> 2) + lane_g + 4 * (i & 3)] = xo[i];
+            for (int i = 0; i < 16; ++i) xl[buf][16 * lane_g + i] = xo[i];
+            if (lane_g == 0) {
+                xl[buf][64] = inv;
+                xl[buf][65] = tfac;
+            }
         }
     }
     __syncthreads();
     double x[16];
-    double ss = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        x[i] = xl[buf][16 * (i >> 2) + lane_g + 4 * (i & 3)];
-        ss = fma(x[i], x[i], ss);
-    }
-    const double alpha = xl[buf][64];
-    const double sigma = allreduce_rowgroups(ss);
-    // prefetch row k+1 of the triangle (not touched by this step)
+    for (int i = 0; i < 16; ++i) x[i] = xl[buf][16 * lane_g + i];
+    const double inv = xl[buf][64], tfac = xl[buf][65];
+    // prefetch row k+2 of the triangle (rows k+1, k+2 are not touched by this step; two steps of distance cover the
+    // L2 round trip, one does not)
+    double Rn3[CPW];
 #pragma unroll
     for (int s = 0; s < CPW; ++s) {
         const int col = 16 * (wave + NW * s) + lane_c;
-        Rn[s] = (k + 1 < nc && col < nc && wave + NW * s < nchunks) ? Rg[(long)(k + 1) * nc + col] : 0.0;
+        Rn3[s] = (k + 2 < nc && col < nc && wave + NW * s < nchunks) ? Rg[(long)(k + 2) * nc + col] : 0.0;
     }
-    if (uniform_of(sigma) != 0.0) {
-        const double q2 = fma(alpha, alpha, sigma);
-        double rs = __builtin_amdgcn_rsq(q2);
-        rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
-        rs = rs * fma(-0.5 * q2 * rs, rs, 1.5);
-        double sq = q2 * rs;
-        sq = fma(fma(-sq, sq, q2), 0.5 * rs, sq);
-        const double dsum = fabs(alpha) + sq;
-        double ri = __builtin_amdgcn_rcp(dsum);
-        ri = ri * fma(-dsum, ri, 2.0);
-        ri = ri * fma(-dsum, ri, 2.0);
-        const double beta = -copysign(sq, alpha);
-        const double inv = copysign(ri, alpha);
-        const double tfac = dsum * rs;
+    if (uniform_of(tfac) != 0.0) {
+        // w_j = tau (R_kj + v^T B_j) in every lane-column, no masks: the pivot lane gets w = alpha - beta (so
+        // R_kk = alpha - w = beta) and c = 1 (its tile entries cancel); finished columns hold (near) zeros
 #pragma unroll
         for (int s = 0; s < CPW; ++s) {
             const int chunk = wave + NW * s;
@@ -493,19 +509,20 @@ __device__ __forceinline__ void tsqr_wide_step(double (&T)[CPW][16], const int p
                     s0 += x[i] * T[s][i];
                     s1 += x[i + 1] * T[s][i + 1];
                 }
-                const double d = allreduce_rowgroups(s0 + s1);
-                const bool trail = col > k;
-                const double wj = trail ? (Rk[s] + d * inv) * tfac : 0.0;
+                const double d = allreduce_rowgroups_lds(red, 16 * lane_g + lane_c, s0 + s1);
+                const double wj = (Rk[s] + d * inv) * tfac;
                 const double cj = wj * inv;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) T[s][i] -= cj * x[i];
-                const double rnew = (col == k) ? beta : Rk[s] - wj;
-                if (lane_g == 0 && col >= k && col < nc) Rg[(long)k * nc + col] = rnew;
+                if (lane_g == 0 && col >= k && col < nc) Rg[(long)k * nc + col] = Rk[s] - wj;
             }
         }
     }
 #pragma unroll
-    for (int s = 0; s < CPW; ++s) Rk[s] = Rn[s];
+    for (int s = 0; s < CPW; ++s) {
+        Rk[s] = Rn[s];
+        Rn[s] = Rn3[s];
+    }
 }
 
 template <int CPW>
@@ -515,6 +532,7 @@ __global__ __launch_bounds__(512) void tsqr_wide_kernel(const double *__restrict
                                                         const long rows_per_blk, double *__restrict__ Rws, const int nc) {
     constexpr int NW = 8;
     __shared__ double xl[2][80];
+    __shared__ double redbuf[NW][64];  // per-wave scratch of the cross-row-group sums
     __shared__ int fnz[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lane_c = lane & 15, lane_g = lane >> 4;
@@ -578,16 +596,18 @@ __global__ __launch_bounds__(512) void tsqr_wide_kernel(const double *__restrict
 #pragma unroll
         for (int w = 1; w < NW; ++w) first_nz = min(first_nz, fnz[w]);
         first_nz = __builtin_amdgcn_readfirstlane(first_nz);
-        double Rk[CPW], Rn[CPW];
+        double Rk[CPW], Rn[CPW];  // rows first_nz and first_nz + 1 of the triangle; step k requests row k + 2
 #pragma unroll
         for (int s = 0; s < CPW; ++s) {
             const int col = 16 * (wave + NW * s) + lane_c;
-            Rk[s] = (first_nz < nc && col < nc && wave + NW * s < nchunks) ? Rg[(long)first_nz * nc + col] : 0.0;
+            const bool ok = col < nc && wave + NW * s < nchunks;
+            Rk[s] = (first_nz < nc && ok) ? Rg[(long)first_nz * nc + col] : 0.0;
+            Rn[s] = (first_nz + 1 < nc && ok) ? Rg[(long)(first_nz + 1) * nc + col] : 0.0;
         }
         for (int p = first_nz >> 4; p < nchunks; ++p) {
 #define FIGH_WSTEP(KK) \
     if (16 * p + KK >= first_nz && 16 * p + KK < nc) \
-        tsqr_wide_step<KK, CPW>(T, p, nchunks, nc, lane_c, lane_g, wave, xl, Rg, Rk, Rn);
+        tsqr_wide_step<KK, CPW>(T, p, nchunks, nc, lane_c, lane_g, wave, xl, redbuf[wave], Rg, Rk, Rn);
             FIGH_WSTEP(0) FIGH_WSTEP(1) FIGH_WSTEP(2) FIGH_WSTEP(3) FIGH_WSTEP(4) FIGH_WSTEP(5) FIGH_WSTEP(6)
             FIGH_WSTEP(7) FIGH_WSTEP(8) FIGH_WSTEP(9) FIGH_WSTEP(10) FIGH_WSTEP(11) FIGH_WSTEP(12) FIGH_WSTEP(13)
             FIGH_WSTEP(14) FIGH_WSTEP(15)
