@@ -583,3 +583,25 @@ def test_sip_qp_terms_match_reference_formulas(lib, golden):
     r_ref = -((1 - alpha) * sf1 * phi_ref.T + sf2 * alpha * np.matmul(tau.T, Wc))
     assert np.abs(P - P_ref).max() <= 1e-11 * np.abs(P_ref).max()
     assert np.abs(r - r_ref).max() <= 1e-11 * np.abs(r_ref).max()
+
+
+# ------------------------------------------------------------------------------------------------ flag sweep
+@pytest.mark.parametrize("flags", range(8))
+def test_regressor_all_flag_combinations(lib, golden, oracle_lib, flags):
+    """has_friction / has_actuator_inertia / has_joint_offset in all eight combinations (regressor.py:55-70, :144-169)
+    on every config, chain kernel and generic tree kernel, zero pattern included; sign(0) = 0 through a zero velocity."""
+    g = golden
+    param = dict(g.param, has_friction=bool(flags & 1), has_actuator_inertia=bool(flags & 2),
+                 has_joint_offset=bool(flags & 4))
+    N = 130
+    q = g["q_big"][:N].copy()
+    v = g["v_big"][:N].copy()
+    a = g["a_big"][:N].copy()
+    v[3] = 0.0  # fs column: np.sign(0) = 0
+    ref = _oracle_W(g, oracle_lib, q, v, a, param=param)
+    for generic in ((False, True) if g.name in ("cfg1_tx40", "cfg2_ur10") else (False,)):
+        W = _gpu_W(g, q, v, a, param=param, generic=generic)
+        assert W.shape == ref.shape
+        assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
+        ext = [c for c in range(ref.shape[1] - (3 if g.coupling else 0)) if c % 14 >= 10]  # Ia fv fs off slots
+        assert np.array_equal(W[:, ext], ref[:, ext])  # copies of v, a, sign(v), 1 and zeros: exact
