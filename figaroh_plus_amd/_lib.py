@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfigh.so")
+# FIGH_LIB_PATH: another build of the same ABI (same-box A/B of kernel variants); default is the in-tree library
+LIB_PATH = os.environ.get("FIGH_LIB_PATH") or os.path.join(_HERE, "libfigh.so")
 
 FIGH_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5
