@@ -49,6 +49,24 @@ def cpu_baseline(flat, seed, n_cpu):
     }
 
 
+def cpu_baseline_fast(flat, seed, n_cpu):
+    """The same pass with the host used well (OpenMP regressor in C, QR without Q): SURVEY 8(d) "fair-fast"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_baseline as cb
+
+    rng = np.random.default_rng(seed)
+    q, v, a = (rng.uniform(-6, 6, (n_cpu, 6)) for _ in range(3))
+    tau = rng.standard_normal(6 * n_cpu)
+    cb.fast_pass(flat, q[:2000], v[:2000], a[:2000], tau[:12000])  # thread pools up
+    t0 = time.perf_counter()
+    _, stages = cb.fast_pass(flat, q, v, a, tau)
+    dt = time.perf_counter() - t0
+    return {"value": n_cpu / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d of the 1e6 UR10 samples, fair-fast structure (one OpenMP C call for the batch regressor, einsum "
+                      "column norms, np.linalg.qr(mode='r') of [W_e tau], regrouped QR of the triangle, triangular solves); "
+                      "stage seconds %s" % (n_cpu, {k: round(x, 2) for k, x in stages.items()})}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +217,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(robot.model.to_flat(), 7, args.cpu_samples)
+            line["cpu_baseline_fast"] = cpu_baseline_fast(robot.model.to_flat(), 7, args.cpu_samples)
         print(json.dumps(line))
     if world > 1:
         barrier()

@@ -66,3 +66,39 @@ def faithful_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8):
         out["phi"] = np.matmul(np.linalg.pinv(W_b), tau)
         t["pinv"] = time.perf_counter() - t0
     return out, t
+
+
+def fast_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8):
+    """"Fair-fast" flavour: the same results with the CPU used well -- one native call for the
+    whole batch (oracle/figh_oracle.c, OpenMP over the samples, W written once in its final layout), column norms
+    without the Gram product, ``np.linalg.qr(mode='r')`` of [W_e tau] (no Q), the regrouped factorisation on the
+    n x n triangle, triangular solves.  Returns (result dict, seconds per stage)."""
+    om = oracle_c.OracleModel(flat)
+    t = {}
+    t0 = time.perf_counter()
+    W = om.build_regressor_basic(q, v, a, 0, 0)
+    t["regressor"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    col_norm = np.einsum("ij,ij->j", W, W)
+    kept = [i for i in range(W.shape[1]) if not col_norm[i] < tol_e]
+    idx_e = [i for i in range(W.shape[1]) if col_norm[i] < tol_e]
+    A = W[:, kept] if tau is None else np.c_[W[:, kept], tau]
+    t["eliminate"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    R = np.linalg.qr(A, mode="r")
+    n = len(kept)
+    d = np.abs(np.diag(R))[:n]
+    idx_base = [i for i in range(n) if d[i] > tol_qr]
+    idx_regroup = [i for i in range(n) if not d[i] > tol_qr]
+    perm = idx_base + idx_regroup + ([n] if tau is not None else [])
+    R2 = np.linalg.qr(R[:, perm], mode="r")
+    r = len(idx_base)
+    import scipy.linalg as sl
+    beta = np.around(sl.solve_triangular(R2[:r, :r], R2[:r, r:n]), 6)
+    t["base_qr"] = time.perf_counter() - t0
+    out = {"idx_e": idx_e, "idx_base": idx_base, "beta": beta}
+    if tau is not None:
+        t0 = time.perf_counter()
+        out["phi"] = sl.solve_triangular(R2[:r, :r], R2[:r, n])
+        t["solve"] = time.perf_counter() - t0
+    return out, t

@@ -191,9 +191,15 @@ int oracle_build_regressor_basic(const oracle_model *m, int mode, int flags, int
     const int nrow = mode == 0 ? nv : 6;
     const int ncols = 14 * nl + ((flags & 8) ? 3 : 0);
     if (mode == 0 && nl != nv) return -1;
+    /* samples are independent: with -fopenmp (the "fair-fast" CPU baseline of bench.py) they are spread over the
+     * host cores, each thread with its own scratch; without it this is the plain sequential loop */
+#pragma omp parallel
+    {
     double *Y = (double *)malloc(sizeof(double) * (size_t)nv * 10 * nl);
     double *work = (double *)malloc(sizeof(double) * 24 * (size_t)m->njoints);
+#pragma omp for schedule(static)
     for (long r = 0; r < (long)nrow * N; ++r) memset(W + r * ldw, 0, sizeof(double) * ncols);
+#pragma omp for schedule(static)
     for (long i = 0; i < N; ++i) {
         const double *qi = q + i * m->nq, *vi = v + i * nv, *ai = a + i * nv;
         oracle_joint_torque_regressor(m, qi, vi, ai, Y, work);
@@ -227,6 +233,7 @@ int oracle_build_regressor_basic(const oracle_model *m, int mode, int flags, int
     }
     free(Y);
     free(work);
+    }
     return 0;
 }
 
