@@ -41,6 +41,11 @@ class _View:
         self.ptr = base.ptr + int(byte_offset)
 
 
+def _dtrtri(R1):
+    from scipy.linalg.lapack import dtrtri
+    return dtrtri(R1, lower=0)  # reads the upper triangle only
+
+
 class IdentificationPipeline:
     def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
                  chunk_samples=None):
@@ -201,8 +206,7 @@ class IdentificationPipeline:
     def _tail(self, d_R, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
         lib, d_idx = _lib.load(), self._d_idx
         R = np.empty((nc, nc))
-        _lib.check(lib.figh_memcpy_d2h(R.ctypes.data, d_R.ptr, R.nbytes))
-        R = np.triu(R)
+        _lib.check(lib.figh_memcpy_d2h(R.ctypes.data, d_R.ptr, R.nbytes))  # upper triangular: the kernels write the zeros
         # tail on the n x n triangle (qrdecomposition.py:215-266): selection on the host, the regrouped
         # factorisation qr(R[:, perm]) again through the TSQR kernel (gather + one wavefront)
         idx_base, idx_regroup = qrd._select(np.diag(R)[:n], params_r, self.tol_qr)
@@ -214,7 +218,11 @@ class IdentificationPipeline:
         _lib.check(lib.figh_memcpy_d2h(R_r.ctypes.data, self._d_R2.ptr, R_r.nbytes))
         r = len(idx_base)
         R1, R2, z = R_r[:r, :r], R_r[:r, r:n], (R_r[:r, n] if with_tau else None)
-        R1_inv = np.linalg.inv(R1)
+        # inv(R1) of qrdecomposition.py:244 by LAPACK's triangular inverse (dtrtri): R1 is upper triangular, and
+        # np.linalg.inv's general LU path pays ~30 us of BLAS thread start-up per call on a many-core host
+        R1_inv, info = _dtrtri(R1)
+        if info != 0:
+            raise np.linalg.LinAlgError("Singular matrix")
         beta = np.around(R1_inv @ R2, 6)
         out = {
             "idx_e": idx_e, "params_r": params_r, "idx_base": idx_base, "beta": beta,
