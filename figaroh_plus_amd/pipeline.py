@@ -186,15 +186,16 @@ class IdentificationPipeline:
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
         _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         col_norm = ex.sum_columns(d_colsq, W.cols)
-        idx_e = [i for i in range(W.cols) if col_norm[i] < self.tol_e]
-        kept = [i for i in range(W.cols) if not col_norm[i] < self.tol_e]
+        small = col_norm < self.tol_e  # regressor.py:271-277 (NaN compares False: kept, as in the reference's loop)
+        idx_e = np.flatnonzero(small).tolist()
+        kept_i32 = np.flatnonzero(~small).astype(np.int32)
+        kept = kept_i32.tolist()
         params_r = [self.names[i] for i in kept]
         n = len(kept)
         # K3: TSQR over the kept columns (+ tau), then the cross-rank stack
         with_tau = self.d_tau is not None
         nc = n + (1 if with_tau else 0)
         d_R, d_idx = self._d_R, self._d_idx
-        kept_i32 = np.asarray(kept, dtype=np.int32)
         _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
         _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R)
         d_stack, count = ex.stack_triangles(d_R, nc)

@@ -42,13 +42,8 @@ def rfactor(W, tau=None, col_idx=None, block_weight=None):
 
 def _select(diagR, params_r, tol_qr):
     assert diagR.shape[0] == len(params_r), "params_r does not have same length with R"
-    idx_base, idx_regroup = [], []
-    for i in range(len(params_r)):
-        if abs(diagR[i]) > tol_qr:
-            idx_base.append(i)
-        else:
-            idx_regroup.append(i)
-    return idx_base, idx_regroup
+    big = np.abs(np.asarray(diagR)) > tol_qr  # qrdecomposition.py:215-221, vectorised (NaN: regrouped, as in the loop)
+    return np.flatnonzero(big).tolist(), np.flatnonzero(~big).tolist()
 
 
 def _regroup(R, idx_base, idx_regroup, with_tau):
