@@ -56,16 +56,15 @@ def _regroup(R, idx_base, idx_regroup, with_tau):
 
 
 def _expressions(params_base, params_regroup, beta, tol_beta=1e-6):
+    """qrdecomposition.py:246-266: ``base + " + " / " - " + str(abs(beta)) + "*" + regrouped`` for abs(beta) >= tol,
+    terms in column order.  Only the non-negligible entries are visited (np.nonzero is row-major, so the order is the
+    reference's double loop); str() of a Python float and of a NumPy float64 are the same shortest repr."""
     out = list(params_base)
-    for i in range(beta.shape[0]):
-        for j in range(beta.shape[1]):
-            b = beta[i, j]
-            if abs(b) < tol_beta:
-                continue
-            if b < -tol_beta:
-                out[i] = out[i] + " - " + str(abs(b)) + "*" + str(params_regroup[j])
-            else:
-                out[i] = out[i] + " + " + str(abs(b)) + "*" + str(params_regroup[j])
+    beta = np.asarray(beta)
+    ii, jj = np.nonzero(~(np.abs(beta) < tol_beta))
+    vals = beta[ii, jj].tolist()
+    for i, j, b in zip(ii.tolist(), jj.tolist(), vals):
+        out[i] = out[i] + (" - " if b < -tol_beta else " + ") + str(abs(b)) + "*" + str(params_regroup[j])
     return out
 
 
