@@ -55,6 +55,7 @@ SIGNATURES = {
     "figh_tsqr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int,
                             C.c_void_p]),
     "figh_tsqr_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "figh_base_permutation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "figh_regressor_colsq": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
     "figh_regressor_tsqr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
@@ -304,6 +305,10 @@ def filtfilt_cols(d_X, rows, cols, ldx, nblocks, form, b, a, zi, padlen, q, d_Y,
                                     a.ctypes.data_as(_c_double_p), nsec, order, zi.ctypes.data_as(_c_double_p), padlen, q,
                                     d_Y.ptr, ldy, C.byref(out)))
     return out.value
+
+
+def base_permutation(d_R, nc, n, tol_qr, d_perm):
+    check(load().figh_base_permutation(d_R.ptr, nc, n, tol_qr, d_perm.ptr))
 
 
 def tsqr_merge(d_Rs, count, nc, d_R):

@@ -1171,6 +1171,32 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const double *__restri
     }
 }
 
+// qrdecomposition.py:215-236: idx_base = {i : |R_ii| > tol}, then the regrouped column order [base | rest | tau].
+// One wave, stable partition by ballot prefix counts; n <= 512.
+__global__ __launch_bounds__(64) void base_permutation_kernel(const double *__restrict__ R, const int nc, const int n,
+                                                              const double tol, int *__restrict__ perm) {
+    const int lane = threadIdx.x;
+    int nbase = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {  // count the base columns
+        const int i = i0 + lane;
+        const bool big = i < n && fabs(R[(long)i * nc + i]) > tol;
+        nbase += __popcll(__ballot(big));
+    }
+    int pb = 0, pr = nbase;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < n;
+        const bool big = in && fabs(R[(long)i * nc + i]) > tol;
+        const unsigned long long mb = __ballot(big), mr = __ballot(in && !big);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (big) perm[pb + __popcll(mb & below)] = i;
+        else if (in) perm[pr + __popcll(mr & below)] = i;
+        pb += __popcll(mb);
+        pr += __popcll(mr);
+    }
+    for (int i = n + lane; i < nc; i += 64) perm[i] = i;  // the tau column stays last
+}
+
 // y[r] = sum_c W[r, idx[c]] x[c]; one wave per row-group, lanes across columns, wave reduction
 __global__ __launch_bounds__(256) void matvec_kernel(const double *__restrict__ W, long rows, long ldw,
                                                      const int *__restrict__ col_idx, int n,
@@ -1439,6 +1465,16 @@ int figh_gather_cols(const double *d_W, int64_t rows, int64_t ldw, const int32_t
     ProfileScope scope("gather_cols");
     hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_W, (long)rows, (long)ldw,
                        d_col_idx, n, d_out, (long)ldo);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int figh_base_permutation(const double *d_R, int nc, int n, double tol_qr, int32_t *d_perm) {
+    FIGH_REQUIRE(d_R && d_perm, "NULL device pointer");
+    FIGH_REQUIRE(n >= 1 && nc >= n && nc <= 512, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    ProfileScope scope("base_permutation");
+    hipLaunchKernelGGL(base_permutation_kernel, dim3(1), dim3(64), 0, stream(), d_R, nc, n, tol_qr, d_perm);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }

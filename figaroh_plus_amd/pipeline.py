@@ -205,18 +205,27 @@ class IdentificationPipeline:
         return self._tail(d_R, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
 
     def _tail(self, d_R, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
-        lib, d_idx = _lib.load(), self._d_idx
-        R = np.empty((nc, nc))
-        _lib.check(lib.figh_memcpy_d2h(R.ctypes.data, d_R.ptr, R.nbytes))  # upper triangular: the kernels write the zeros
-        # tail on the n x n triangle (qrdecomposition.py:215-266): selection on the host, the regrouped
-        # factorisation qr(R[:, perm]) again through the TSQR kernel (gather + one wavefront)
-        idx_base, idx_regroup = qrd._select(np.diag(R)[:n], params_r, self.tol_qr)
-        perm = np.asarray(list(idx_base) + list(idx_regroup) + ([n] if with_tau else []), dtype=np.int32)
-        _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, perm.ctypes.data, perm.nbytes))
-        _lib.gather_cols(d_R, nc, nc, d_idx, nc, self._d_Rp, nc)
-        _lib.tsqr(self._d_Rp, nc, nc, None, nc, None, None, self._d_R2)
-        R_r = np.empty((nc, nc))
-        _lib.check(lib.figh_memcpy_d2h(R_r.ctypes.data, self._d_R2.ptr, R_r.nbytes))
+        lib = _lib.load()
+        # tail on the n x n triangle (qrdecomposition.py:215-266).  The rank decision |R_ii| > tol and the regrouped
+        # order [base | rest | tau] are formed on the device (figh_base_permutation) and the regrouped factorisation
+        # qr(R[:, perm]) goes through the TSQR kernel again (column gather in the kernel, one wavefront), so the whole
+        # tail needs ONE host round trip: R, the regrouped triangle and the permutation come back in one copy.
+        words = 2 * nc * nc + (nc + 1) // 2
+        pack = getattr(self, "_d_pack", None)
+        if pack is None or pack.size < words:
+            pack = self._d_pack = _lib.DeviceArray((words,), np.float64)
+        _lib.check(lib.figh_memcpy_d2d(pack.ptr, d_R.ptr, nc * nc * 8))
+        d_perm = _View(pack, 2 * nc * nc * 8)
+        _lib.base_permutation(d_R, nc, n, self.tol_qr, d_perm)
+        _lib.tsqr(d_R, nc, nc, d_perm, nc, None, None, _View(pack, nc * nc * 8))
+        host = np.empty(words)
+        _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, pack.ptr, host.nbytes))
+        R = host[:nc * nc].reshape(nc, nc)          # upper triangular: the kernels write the zeros
+        R_r = host[nc * nc:2 * nc * nc].reshape(nc, nc)
+        perm = host[2 * nc * nc:].view(np.int32)[:nc]
+        r = int(np.count_nonzero(np.abs(np.diag(R)[:n]) > self.tol_qr))
+        idx_base, idx_regroup = perm[:r].tolist(), perm[r:n].tolist()
+        assert len(params_r) == n, "params_r does not have same length with R"
         r = len(idx_base)
         R1, R2, z = R_r[:r, :r], R_r[:r, r:n], (R_r[:r, n] if with_tau else None)
         # inv(R1) of qrdecomposition.py:244 by LAPACK's triangular inverse (dtrtri): R1 is upper triangular, and

@@ -121,6 +121,10 @@ int figh_block_sqnorm(const double *d_a, const double *d_b, int64_t rows, int nb
  * Q^T tau (first n entries) and the residual norm (entry nc-1).  R is defined up to row signs, like LAPACK's. */
 int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
               const double *h_block_weight, int nblocks, double *d_R_out);
+/* The rank decision and the regrouped column order on the device (qrdecomposition.py:215-236): d_perm receives
+ * [i : |R_ii| > tol_qr, ascending] followed by the remaining i < n, followed by n .. nc-1 (the tau column); the regrouped
+ * factorisation qr([W1 W2 tau]) is then figh_tsqr(d_R, nc, nc, d_perm, nc, NULL, ...) with no host round trip. */
+int figh_base_permutation(const double *d_R, int nc, int n, double tol_qr, int32_t *d_perm);
 /* Sample-sharded reduction step: QR of `count` stacked nc x nc R factors (d_Rs: count*nc x nc) into one. */
 int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out);
 
