@@ -19,17 +19,20 @@ def main():
                        "scratch_size from kernels").fetchall()
     agg = {}
     for name, dur, gx, wx, lds, vg, ag, sg, scr in rows:
-        a = agg.setdefault(short(name), {"n": 0, "tot": 0, "min": 1 << 62, "max": 0, "meta": (gx, wx, lds, vg, ag, sg, scr)})
+        # one line per (kernel, launch shape): the full-size TSQR launch and the one-wave regrouped factorisation share a
+        # kernel name, and so do the merge levels
+        key = "%s [grid %d]" % (short(name), gx)
+        a = agg.setdefault(key, {"n": 0, "tot": 0, "min": 1 << 62, "max": 0, "meta": (gx, wx, lds, vg, ag, sg, scr)})
         a["n"] += 1
         a["tot"] += dur
         a["min"] = min(a["min"], dur)
         a["max"] = max(a["max"], dur)
     total = sum(a["tot"] for a in agg.values()) or 1
     print("# rocprofv3 --kernel-trace --stats summary of %s" % db)
-    print("%-52s %6s %12s %11s %11s %11s %6s  %s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%", "grid/wg lds vgpr agpr sgpr scratch"))
+    print("%-66s %6s %12s %11s %11s %11s %6s  %s" % ("kernel [launch shape]", "calls", "total_us", "avg_us", "min_us", "max_us", "%", "grid/wg lds vgpr agpr sgpr scratch"))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["tot"]):
-        print("%-52s %6d %12.1f %11.2f %11.2f %11.2f %6.2f  %s" % (
-            k[:52], a["n"], a["tot"] / 1e3, a["tot"] / a["n"] / 1e3, a["min"] / 1e3, a["max"] / 1e3, 100.0 * a["tot"] / total,
+        print("%-66s %6d %12.1f %11.2f %11.2f %11.2f %6.2f  %s" % (
+            k[:66], a["n"], a["tot"] / 1e3, a["tot"] / a["n"] / 1e3, a["min"] / 1e3, a["max"] / 1e3, 100.0 * a["tot"] / total,
             "%d/%d %d %d %d %d %d" % a["meta"]))
     if "--pmc" in sys.argv:
         try:
