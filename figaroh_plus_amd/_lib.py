@@ -54,6 +54,8 @@ SIGNATURES = {
     "figh_block_sqnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "figh_tsqr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int,
                             C.c_void_p]),
+    "figh_tsqr_structured": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, _c_double_p,
+                                       C.c_int, _c_int32_p, C.c_int, C.c_void_p]),
     "figh_tsqr_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "figh_base_permutation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "figh_regressor_colsq": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
@@ -255,13 +257,21 @@ def block_sqnorm(d_a, d_b, rows, nblocks, d_out):
     check(load().figh_block_sqnorm(d_a.ptr, d_b.ptr if d_b is not None else None, rows, nblocks, d_out.ptr))
 
 
-def tsqr(d_W, rows, ldw, d_idx, n, d_tau, block_weight, d_R):
+def tsqr(d_W, rows, ldw, d_idx, n, d_tau, block_weight, d_R, first_cols=None):
+    """``first_cols``: structure hint (figh_tsqr_structured): per row block, the first gathered column that can be
+    non-zero."""
     bw = None
     nb = 0
     if block_weight is not None:
         bwa = _f64(block_weight)
         bw = bwa.ctypes.data_as(_c_double_p)
         nb = len(bwa)
+    if first_cols is not None:
+        fc = _i32(first_cols)
+        check(load().figh_tsqr_structured(d_W.ptr, rows, ldw, d_idx.ptr if d_idx is not None else None, n,
+                                          d_tau.ptr if d_tau is not None else None, bw, nb,
+                                          fc.ctypes.data_as(_c_int32_p), len(fc), d_R.ptr))
+        return
     check(load().figh_tsqr(d_W.ptr, rows, ldw, d_idx.ptr if d_idx is not None else None, n,
                            d_tau.ptr if d_tau is not None else None, bw, nb, d_R.ptr))
 

@@ -219,7 +219,14 @@ template <int NCC, int NRC, bool TRI, bool PROF = false, bool LDSRED = false>
 __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
     const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
-    double *__restrict__ Rws, const int nc, const int dbg, const int out_rows, long long *__restrict__ prof = nullptr) {
+    double *__restrict__ Rws, const int nc, const int dbg, const int out_rows, long long *__restrict__ prof = nullptr,
+    const int *__restrict__ tile_first = nullptr) {
+    // tile_first[t] (always a valid array; zeros without a structure hint, figh_tsqr_structured): the first kept column
+    // that can hold a non-zero in tile t.  Lanes in front of it are not read at all (their registers are zeroed, the
+    // loads run under a narrower EXEC mask): in the joint-major regressor of a chain, row block j only involves the
+    // links >= j, so 41 % of the kept entries of UR10 -- and of this kernel's HBM reads -- are known zeros.  (The array is
+    // unconditional on purpose: a `hint != nullptr` test inside the tile loop gets the loop unswitched and costs 70
+    // spilled registers.)
     // PROF (FIGH_TSQR_DBG & 4): per-wave s_memtime totals {kernel, load + delivery, factorisation, column steps}
     long long pc_load = 0, pc_fact = 0, pc_steps = 0;
     const long long pc_begin = PROF ? (long long)__builtin_readcyclecounter() : 0;
@@ -276,18 +283,24 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     // once, under one EXEC mask per chunk.  The requests for the NEXT tile's chunk P are issued as soon as panel P of
     // the current tile is finished (its registers are dead from then on), so most of a tile's HBM latency is covered
     // by the wave's own remaining panels and only the last chunk (+ tau) is requested at the top of the iteration.
-    auto load_chunk = [&](auto CC, const long r0) {
+    auto load_chunk = [&](auto CC, const long r0, const int fpos) {
         constexpr int cc = decltype(CC)::value;
-        if (wlive[cc]) {
+        // lanes whose column lies in front of the tile's first possible non-zero (hint) are not read: their registers
+        // are zeroed and the loads run under the narrower EXEC mask
+        if (fpos > 16 * cc) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) S.T[cc][i] = 0.0;
+        }
+        if (wlive[cc] && 16 * cc + S.lane_c >= fpos) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i) S.T[cc][i] = (W + (r0 + 16 * (i >> 2) + 4 * (i & 3)) * ldw)[loff[cc]];
         }
     };
-    auto load_head_chunks = [&](const long r0) {  // chunks 0 .. NCC-2
-        if constexpr (NCC > 1) load_chunk(std::integral_constant<int, 0>{}, r0);
-        if constexpr (NCC > 2) load_chunk(std::integral_constant<int, 1>{}, r0);
-        if constexpr (NCC > 3) load_chunk(std::integral_constant<int, 2>{}, r0);
-        if constexpr (NCC > 4) load_chunk(std::integral_constant<int, 3>{}, r0);
+    auto load_head_chunks = [&](const long r0, const int fpos) {  // chunks 0 .. NCC-2
+        if constexpr (NCC > 1) load_chunk(std::integral_constant<int, 0>{}, r0, fpos);
+        if constexpr (NCC > 2) load_chunk(std::integral_constant<int, 1>{}, r0, fpos);
+        if constexpr (NCC > 3) load_chunk(std::integral_constant<int, 2>{}, r0, fpos);
+        if constexpr (NCC > 4) load_chunk(std::integral_constant<int, 3>{}, r0, fpos);
     };
 
     bool prefetched = false;
@@ -332,12 +345,14 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
             r0n = (r0n / blk) * blk + (r0n % blk) % (8 * M);
         }
         const long long pc_a = PROF ? (long long)__builtin_readcyclecounter() : 0;
+        const int fpos = fast ? __builtin_amdgcn_readfirstlane(pad + tile_first[t]) : 0;
+        const int fposn = next_fast ? __builtin_amdgcn_readfirstlane(pad + tile_first[tn]) : 0;
         if (fast) {
-            if (!prefetched) load_head_chunks(r0);
+            if (!prefetched) load_head_chunks(r0, fpos);
             // the last chunk (+ tau) is live until the end of the previous tile: requested here.  (Requesting it into
             // a separate 16-double buffer during the last panel was measured: the load phase shrinks, the panels
             // slow down by the same amount -- 256 VGPRs -- no net gain.)
-            load_chunk(std::integral_constant<int, NCC - 1>{}, r0);
+            load_chunk(std::integral_constant<int, NCC - 1>{}, r0, fpos);
             if (tau_lane) {
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) S.T[NCC - 1][i] = (tau + r0 + 16 * (i >> 2) + 4 * (i & 3))[S.lane_g];
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
 
         tsqr2_panels<0, NCC, NRC, TRI, LDSRED>(S, first_nz, [&](auto P) {
             if constexpr (decltype(P)::value < NCC - 1) {
-                if (next_fast) load_chunk(P, r0n);
+                if (next_fast) load_chunk(P, r0n, fposn);
             }
         });
         prefetched = next_fast;
@@ -1260,6 +1275,32 @@ static size_t tsqr2_lds_bytes(int ncc, int nc) {
     return sizeof(double) * (64 + 256 * (size_t)(ncc * ncc - (ncc * (ncc - 1)) / 2) - skip);
 }
 
+// per-tile structure hint of the register-tile kernel: g_tile_hint (set by figh_tsqr_structured for the next level-0
+// launch) or an all-zero array
+static const int *g_tile_hint = nullptr;
+
+__global__ __launch_bounds__(256) void tile_hint_kernel(const int *__restrict__ first, const long hint_rows,
+                                                        const long rows, const long ntiles, int *__restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const long r0 = t * 64, r1 = (r0 + 63 < rows ? r0 + 63 : rows - 1);
+    int f = first[r0 / hint_rows];
+    for (long b = r0 / hint_rows + 1; b <= r1 / hint_rows; ++b) f = min(f, first[b]);
+    out[t] = f;
+}
+
+static const int *tile_hint_or_zeros(long ntiles) {
+    if (g_tile_hint) return g_tile_hint;
+    static size_t zeroed = 0;
+    const size_t need = sizeof(int) * (size_t)(ntiles + 1);
+    int *z = static_cast<int *>(workspace(need, 15));
+    if (z && zeroed < need) {  // (re)allocated: workspace() hands out at least `need` bytes, growing by 25 %
+        if (hipMemsetAsync(z, 0, need, stream()) != hipSuccess) return nullptr;
+        zeroed = need;
+    }
+    return z;
+}
+
 // one TSQR level: rows of (W, ldw) -> nw triangles in Rws.  Returns nw (>0) or a negative status.
 static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
                        const double *d_blkw, long rows_per_blk, int nc, long target_waves, long align,
@@ -1275,6 +1316,11 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
     const long nw = (rows + rpw - 1) / rpw;
     *nw_out = nw;
     dim3 grid((unsigned)nw), block(64);
+    const int *th = nullptr;  // per-tile structure hint of the register-tile kernel (64-row tiles)
+    if (nc <= 80 && !g_force_v1) {
+        th = tile_hint_or_zeros((rows + 63) / 64);
+        if (!th) return FIGH_ERR_ALLOC;
+    }
 #define FIGH_TSQR_LAUNCH(CPL, MM, RL)                                                                          \
     hipLaunchKernelGGL((tsqr_kernel<CPL, MM, RL>), grid, block, 0, stream(), W, rows, ldw, col_idx, n, tau,     \
                        d_blkw, rows_per_blk, rpw, Rws_out, nc)
@@ -1293,12 +1339,12 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
         const size_t lds2 = tsqr2_lds_bytes(4, nc);
         if (tri)
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
-                               d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
+                               d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr, th);
         else if (g_dbg & 4) {
             long long *prof = static_cast<long long *>(workspace(sizeof(long long) * 4 * nw, 6));
             if (!prof) return FIGH_ERR_ALLOC;
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, true>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n,
-                               tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, prof);
+                               tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, prof, th);
             std::vector<long long> h(4 * nw);
             FIGH_HIP(hipMemcpyAsync(h.data(), prof, sizeof(long long) * 4 * nw, hipMemcpyDeviceToHost, stream()));
             FIGH_HIP(hipStreamSynchronize(stream()));
@@ -1329,14 +1375,14 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
             }
         } else if (g_dbg & 64)  // A/B: permlane-swap reduction instead of the LDS one
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, false, false>), grid, block, lds2, stream(), W, rows, ldw,
-                               col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr);
+                               col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr, th);
         else
             hipLaunchKernelGGL((tsqr2_kernel<4, 4, false, false, true>), grid, block, lds2, stream(), W, rows, ldw,
-                               col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr);
+                               col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr, th);
     } else if (nc <= 80 && !g_force_v1) {
         const size_t lds2 = tsqr2_lds_bytes(5, nc);
         hipLaunchKernelGGL((tsqr2_kernel<5, 4, false>), grid, block, lds2, stream(), W, rows, ldw, col_idx, n, tau,
-                           d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows);
+                           d_blkw, rows_per_blk, Rws_out, nc, g_dbg, out_rows, nullptr, th);
     } else if (nc <= 64) FIGH_TSQR_LAUNCH(1, 64, true);
     else if (nc <= 512 && !g_force_v1) {
         // column-split workgroups: nw here counts workgroups (one private triangle each)
@@ -1601,6 +1647,41 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
     return tsqr_reduce(Rws, nw, nc, d_R_out, padded != 0);
 }
 
+
+int figh_tsqr_structured(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
+                         const double *d_tau, const double *h_block_weight, int nblocks, const int32_t *h_first_col,
+                         int nfirst, double *d_R_out) {
+    FIGH_REQUIRE(h_first_col && nfirst > 0 && rows > 0 && rows % nfirst == 0, "rows must be a multiple of the hint blocks");
+    for (int b = 0; b < nfirst; ++b) FIGH_REQUIRE(h_first_col[b] >= 0 && h_first_col[b] <= n, "first column out of range");
+    if (int rc = ensure_device()) return rc;
+    const int nc = n + (d_tau ? 1 : 0);
+    if (nc > 80 || g_force_v1)  // only the register-tile kernel uses the hint
+        return figh_tsqr(d_W, rows, ldw, d_col_idx, n, d_tau, h_block_weight, nblocks, d_R_out);
+    // the per-tile form of the hint is cached: the pipeline passes the same structure every step
+    static std::vector<int32_t> cached_first;
+    static int64_t cached_rows = -1;
+    static const int *cached_ptr = nullptr;
+    const long ntiles = (rows + 63) / 64;
+    int *d_tile = static_cast<int *>(workspace(sizeof(int) * (size_t)(ntiles + 1), 14));
+    if (!d_tile) return FIGH_ERR_ALLOC;
+    if (cached_ptr != d_tile || cached_rows != rows || cached_first.size() != (size_t)nfirst ||
+        !std::equal(cached_first.begin(), cached_first.end(), h_first_col)) {
+        int *d_first = static_cast<int *>(workspace(sizeof(int) * nfirst, 7));
+        if (!d_first) return FIGH_ERR_ALLOC;
+        FIGH_HIP(hipMemcpyAsync(d_first, h_first_col, sizeof(int) * nfirst, hipMemcpyHostToDevice, stream()));
+        hipLaunchKernelGGL(tile_hint_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream(), d_first,
+                           (long)(rows / nfirst), (long)rows, ntiles, d_tile);
+        FIGH_HIP(hipGetLastError());
+        FIGH_HIP(hipStreamSynchronize(stream()));  // h_first_col is the caller's memory
+        cached_first.assign(h_first_col, h_first_col + nfirst);
+        cached_rows = rows;
+        cached_ptr = d_tile;
+    }
+    g_tile_hint = d_tile;
+    const int rc = figh_tsqr(d_W, rows, ldw, d_col_idx, n, d_tau, h_block_weight, nblocks, d_R_out);
+    g_tile_hint = nullptr;
+    return rc;
+}
 
 int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out) {
     FIGH_REQUIRE(d_Rs && d_R_out, "NULL device pointer");

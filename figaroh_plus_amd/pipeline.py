@@ -165,6 +165,16 @@ class IdentificationPipeline:
             _lib.tsqr_merge(d_stack, count, nc, d_R)
         return self._tail(d_R, n, nc, params_r, idx_e, col_norm, with_tau, rps * self.N * ex.world_size, strings)
 
+    def _structure_hint(self, mode, kept_i32):
+        """Joint-torque regressor of single-dof joints (regressor.py:45-87): the rows of joint j (row block j of N rows)
+        only involve the links of j's subtree, which are numbered from j on -- the columns in front of 14 j are zeros
+        written by K1.  Returns, per row block, how many kept columns lie in front (None when the structure is not
+        guaranteed: external-wrench mode, multi-dof joints)."""
+        m = self.robot.model
+        if mode != _lib.MODE_JOINT_TORQUE or m.nv != m.njoints - 1 or self.N < 64:
+            return None
+        return np.searchsorted(kept_i32, 14 * np.arange(m.nv)).astype(np.int32)
+
     def run(self, strings=True):
         if self._chunked():
             return self._run_chunked(strings)
@@ -197,7 +207,7 @@ class IdentificationPipeline:
         nc = n + (1 if with_tau else 0)
         d_R, d_idx = self._d_R, self._d_idx
         _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
-        _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R)
+        _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R, first_cols=self._structure_hint(mode, kept_i32))
         d_stack, count = ex.stack_triangles(d_R, nc)
         if count > 1:
             _lib.tsqr_merge(d_stack, count, nc, self._d_Rm)

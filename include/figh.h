@@ -121,6 +121,14 @@ int figh_block_sqnorm(const double *d_a, const double *d_b, int64_t rows, int nb
  * Q^T tau (first n entries) and the residual norm (entry nc-1).  R is defined up to row signs, like LAPACK's. */
 int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
               const double *h_block_weight, int nblocks, double *d_R_out);
+/* figh_tsqr with a structure hint: the rows are nfirst consecutive blocks of rows/nfirst rows, and in block b the
+ * gathered columns 0 .. h_first_col[b]-1 are EXACTLY zero (the caller's guarantee; 0 <= h_first_col[b] <= n).  That is
+ * the shape of build_regressor_basic's W in joint-torque mode (regressor.py:45-87): row block j (the rows of joint j)
+ * only involves the links of j's subtree, i.e. the columns from 14 j on.  The register-tile kernel (n <= 79) then does
+ * not read those entries at all (41 % of the reads for UR10).  Same result as figh_tsqr. */
+int figh_tsqr_structured(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
+                         const double *d_tau, const double *h_block_weight, int nblocks, const int32_t *h_first_col,
+                         int nfirst, double *d_R_out);
 /* The rank decision and the regrouped column order on the device (qrdecomposition.py:215-236): d_perm receives
  * [i : |R_ii| > tol_qr, ascending] followed by the remaining i < n, followed by n .. nc-1 (the tau column); the regrouped
  * factorisation qr([W1 W2 tau]) is then figh_tsqr(d_R, nc, nc, d_perm, nc, NULL, ...) with no host round trip. */
