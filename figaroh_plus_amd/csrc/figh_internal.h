@@ -61,6 +61,8 @@ extern "C" int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, co
                                 const double *d_tau, const double *h_block_weight, int nblocks, double *d_tri_out,
                                 int64_t capacity, int64_t *count_out, double **ws_out, int *padded_out);
 extern "C" int64_t figh_tsqr_level0_capacity(int nc);
+extern "C" int figh_tsqr_hint_begin(const int32_t *h_first_col, int nfirst, int64_t rows, int n, int nc);
+extern "C" void figh_tsqr_hint_end(void);
 
 namespace figh {
 

@@ -1648,15 +1648,13 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
 }
 
 
-int figh_tsqr_structured(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
-                         const double *d_tau, const double *h_block_weight, int nblocks, const int32_t *h_first_col,
-                         int nfirst, double *d_R_out) {
+// internal (figh_internal.h): install / remove the structure hint for the next level-0 launches on `rows` rows
+int figh_tsqr_hint_begin(const int32_t *h_first_col, int nfirst, int64_t rows, int n, int nc) {
     FIGH_REQUIRE(h_first_col && nfirst > 0 && rows > 0 && rows % nfirst == 0, "rows must be a multiple of the hint blocks");
     for (int b = 0; b < nfirst; ++b) FIGH_REQUIRE(h_first_col[b] >= 0 && h_first_col[b] <= n, "first column out of range");
     if (int rc = ensure_device()) return rc;
-    const int nc = n + (d_tau ? 1 : 0);
-    if (nc > 80 || g_force_v1)  // only the register-tile kernel uses the hint
-        return figh_tsqr(d_W, rows, ldw, d_col_idx, n, d_tau, h_block_weight, nblocks, d_R_out);
+    g_tile_hint = nullptr;
+    if (nc > 80 || g_force_v1) return FIGH_OK;  // only the register-tile kernel uses the hint
     // the per-tile form of the hint is cached: the pipeline passes the same structure every step
     static std::vector<int32_t> cached_first;
     static int64_t cached_rows = -1;
@@ -1678,8 +1676,16 @@ int figh_tsqr_structured(const double *d_W, int64_t rows, int64_t ldw, const int
         cached_ptr = d_tile;
     }
     g_tile_hint = d_tile;
+    return FIGH_OK;
+}
+void figh_tsqr_hint_end(void) { g_tile_hint = nullptr; }
+
+int figh_tsqr_structured(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
+                         const double *d_tau, const double *h_block_weight, int nblocks, const int32_t *h_first_col,
+                         int nfirst, double *d_R_out) {
+    if (int rc = figh_tsqr_hint_begin(h_first_col, nfirst, rows, n, n + (d_tau ? 1 : 0))) return rc;
     const int rc = figh_tsqr(d_W, rows, ldw, d_col_idx, n, d_tau, h_block_weight, nblocks, d_R_out);
-    g_tile_hint = nullptr;
+    figh_tsqr_hint_end();
     return rc;
 }
 

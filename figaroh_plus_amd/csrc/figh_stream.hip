@@ -85,6 +85,27 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     double *stack = static_cast<double *>(workspace(sizeof(double) * (size_t)nchunks * per_chunk * nc * nc, 11));
     if (!Wc || (d_tau && !tc) || !stack) return FIGH_ERR_ALLOC;
     const int nq = model->host.nq, nv = model->host.nv;
+    // joint-torque regressor of single-dof joints: the rows of joint j only involve the links from j on, so the kept
+    // columns in front of 14 j are exact zeros in row block j -- the structure hint of figh_tsqr_structured
+    std::vector<int32_t> first;
+    if (mode == FIGH_MODE_JOINT_TORQUE && nv == model->host.njoints - 1 && nc <= 80 && cs >= 64) {
+        std::vector<int32_t> cols(n);
+        if (d_col_idx) {
+            if (int rc = figh_memcpy_d2h(cols.data(), d_col_idx, sizeof(int32_t) * n)) return rc;
+        } else {
+            for (int c = 0; c < n; ++c) cols[c] = c;
+        }
+        bool sorted = true;
+        for (int c = 1; c < n; ++c) sorted = sorted && cols[c - 1] < cols[c];
+        if (sorted) {
+            first.resize(rps);
+            for (int j = 0; j < rps; ++j) {
+                int f = 0;
+                while (f < n && cols[f] < 14 * j) ++f;
+                first[j] = f;
+            }
+        }
+    }
     int64_t have = 0;
     for (int64_t lo = 0; lo < N; lo += cs) {
         const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
@@ -95,9 +116,13 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
             FIGH_HIP(hipMemcpy2DAsync(tc, sizeof(double) * nc_, d_tau + lo, sizeof(double) * N, sizeof(double) * nc_, rps,
                                       hipMemcpyDeviceToDevice, stream()));
         int64_t got = 0;
-        if (int rc = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ncols, d_col_idx, n, tc, h_block_weight, nblocks,
-                                      stack + (size_t)have * nc * nc, per_chunk, &got, nullptr, nullptr))
-            return rc;
+        if (!first.empty() && nc_ >= 64) {
+            if (int rc = figh_tsqr_hint_begin(first.data(), rps, (int64_t)rps * nc_, n, nc)) return rc;
+        }
+        const int rc0 = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ncols, d_col_idx, n, tc, h_block_weight, nblocks,
+                                         stack + (size_t)have * nc * nc, per_chunk, &got, nullptr, nullptr);
+        figh_tsqr_hint_end();
+        if (rc0) return rc0;
         have += got;
     }
     FIGH_REQUIRE(have < (1LL << 31), "too many level-0 triangles");
