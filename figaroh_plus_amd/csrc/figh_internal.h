@@ -59,12 +59,17 @@ void *workspace(size_t bytes, int slot);
 // internal (not part of include/figh.h): level 0 of the TSQR only, see figh_linalg.hip
 extern "C" int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
                                 const double *d_tau, const double *h_block_weight, int nblocks, double *d_tri_out,
-                                int64_t capacity, int64_t *count_out, double **ws_out, int *padded_out);
+                                int64_t capacity, int64_t *count_out, double **ws_out);
 extern "C" int64_t figh_tsqr_level0_capacity(int nc);
 extern "C" int figh_tsqr_hint_begin(const int32_t *h_first_col, int nfirst, int64_t rows, int n, int nc);
 extern "C" void figh_tsqr_hint_end(void);
 
 namespace figh {
+
+// figh_tsqr_wide.hip: the blocked (compact-WY, MFMA) level for nc > 80 columns
+long tsqr_wide_workgroups(int nc, int cus);
+int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
+                     const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out);
 
 #define FIGH_HIP(expr)                                                                          \
     do {                                                                                        \

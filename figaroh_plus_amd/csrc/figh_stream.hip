@@ -120,7 +120,7 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
             if (int rc = figh_tsqr_hint_begin(first.data(), rps, (int64_t)rps * nc_, n, nc)) return rc;
         }
         const int rc0 = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ncols, d_col_idx, n, tc, h_block_weight, nblocks,
-                                         stack + (size_t)have * nc * nc, per_chunk, &got, nullptr, nullptr);
+                                         stack + (size_t)have * nc * nc, per_chunk, &got, nullptr);
         figh_tsqr_hint_end();
         if (rc0) return rc0;
         have += got;

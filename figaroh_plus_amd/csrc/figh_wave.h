@@ -1,0 +1,83 @@
+// Wave-level building blocks shared by the TSQR kernels (gfx950, wave64).
+//
+// Register tiles are kept in the v_mfma_f64_16x16x4 C/D layout: lane = 16*g + c (g = lane >> 4 is the "row group",
+// c = lane & 15 the lane-column) holds rows 16*rc + g + 4*r (rc = 16-row chunk, r = 0..3) of column c.  In that layout
+//   - a column of the tile inside one row group is a DPP row_newbcast (a VALU operand modifier, no LDS crossbar),
+//   - a sum over the rows of a column is a per-lane sum followed by a sum over the four row groups,
+//   - register r of a 16-row chunk IS the A/B operand of K-slice r of the f64 MFMA (A[i = c][k = g], B[k = g][j = c]).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace figh {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int K>
+__device__ __forceinline__ double row_bcast(double x) {  // value of lane-column K of my row group
+    // v_mov_b64_dpp: gfx90a+ allows 64-bit DPP for row_newbcast, one instruction per double
+    return __longlong_as_double(
+        __builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(x), 0x150 + K, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ double allreduce_rowgroups(double x) {  // sum over lanes c, c+16, c+32, c+48
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    u32x2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    u32x2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(y);
+    hi = __double2hiint(y);
+    a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+__device__ __forceinline__ double uniform_of(double x) {  // SGPR copy of a value that is identical in all lanes
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
+// Sum over the four row groups through the wave's own 512 B of LDS: one ds_write_b64 + three ds_read_b64 + three
+// v_add_f64 instead of 4 v_mov + 4 v_permlane*_swap + 2 adds.  Every row group adds the same two pairs in the same
+// order: the result is bit-identical in all lanes.  (Same-box A/B on the UR10 problem, round 1: 1.034 vs 1.080 ms.)
+__device__ __forceinline__ double allreduce_rowgroups_lds(double *red, const int lane, const double x) {
+    red[lane] = x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double a = red[lane ^ 16], b = red[lane ^ 32], c = red[lane ^ 48];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return (x + a) + (b + c);
+}
+
+// acc += (value of pv in lane-column K of my row group) * b as ONE instruction: gfx90a+ allow a DPP row_newbcast
+// operand on the DP ALU v_fmac_f64, so the pivot column is never materialised in registers (no v_mov_b64_dpp per
+// row).  The compiler does not form this instruction by itself.  Hazard: a VGPR written by a VALU instruction needs
+// 2 wait states before a DPP read -- callers order their updates so that a register is never read through DPP by the
+// instruction right after the one that wrote it.
+template <int K>
+__device__ __forceinline__ void fmac_bcast(double &acc, const double pv, const double b) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pv), "v"(b), "n"(K));
+}
+
+// Householder scalars of the stacked column [alpha; x], sigma = x^T x != 0 (LAPACK dlarfg without the rescaling
+// loop): beta = -sign(alpha) sqrt(alpha^2 + sigma), inv = 1 / (alpha - beta) = sign(alpha) / (|alpha| + s),
+// tfac = tau = (beta - alpha) / beta = (|alpha| + s) / s.  v_rsq_f64 / v_rcp_f64 seeds (2^-24 accurate) + two Newton
+// steps each instead of the IEEE sqrt and two divisions.
+__device__ __forceinline__ void householder_scalars(const double alpha, const double sigma, double &inv, double &tfac) {
+    const double q2 = fma(alpha, alpha, sigma);
+    const double hq = -0.5 * q2;
+    double rs = __builtin_amdgcn_rsq(q2);
+    rs = rs * fma(hq * rs, rs, 1.5);
+    rs = rs * fma(hq * rs, rs, 1.5);
+    const double dsum = fma(q2, rs, fabs(alpha));  // |alpha| + s
+    double ri = __builtin_amdgcn_rcp(dsum);
+    ri = ri * fma(-dsum, ri, 2.0);
+    ri = ri * fma(-dsum, ri, 2.0);
+    inv = copysign(ri, alpha);
+    tfac = dsum * rs;
+}
+
+}  // namespace figh
