@@ -745,7 +745,7 @@ int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t
     FIGH_REQUIRE(rows > 0 && n > 0 && ldw > 0, "bad shape");
     const int nc = n + (d_tau ? 1 : 0);
     FIGH_REQUIRE(nc <= 512, "figh_tsqr: more than 512 columns not supported yet");
-    FIGH_REQUIRE(ldw < (1L << 24), "figh_tsqr: leading dimension must be below 2^24 elements");
+    FIGH_REQUIRE(ldw < (1L << 22), "figh_tsqr: leading dimension must be below 2^22 elements");
     if (int rc = ensure_device()) return rc;
     const double *d_blkw = nullptr;
     long rows_per_blk = 1;

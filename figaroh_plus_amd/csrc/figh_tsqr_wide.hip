@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "figh_internal.h"
 #include "figh_wave.h"
@@ -45,28 +46,62 @@ namespace figh {
 
 namespace {
 
+// in-kernel s_memtime accounting, ablation build only (FIGH_WY_PROF=1): per wave {kernel, tile top, first panel,
+// look-ahead chunk update, look-ahead panel, trailing updates, barrier waits}
+#ifdef FIGH_ABLATION
+#define FIGH_PROF_DECL long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_ = __builtin_readcyclecounter(); const long long pbegin_ = pt_;
+#define FIGH_PROF_ADD(k) do { const long long now_ = __builtin_readcyclecounter(); pc_[k] += now_ - pt_; pt_ = now_; } while (0)
+#define FIGH_PROF_STORE(ptr, w, nw) do { if ((ptr) && lane == 0) { pc_[0] = __builtin_readcyclecounter() - pbegin_; for (int k_ = 0; k_ < 12; ++k_) (ptr)[((long)blockIdx.x * (nw) + (w)) * 12 + k_] = pc_[k_]; } } while (0)
+#else
+#define FIGH_PROF_DECL
+#define FIGH_PROF_ADD(k) do {} while (0)
+#define FIGH_PROF_STORE(ptr, w, nw) do {} while (0)
+#endif
+
 constexpr int kLdv = 17;  // LDS row stride of V (doubles): the transposed reads of B -= V Wm hit 16 different banks
 
-// sum over the finished reflectors m < KK of Trow[m] * vg(lane-column m): DPP lane selects must be immediates
-template <int M0, int KK>
+constexpr int kLdt = 17;  // LDS row stride of T (doubles): T[row][col] at row * kLdt + col
+
+// Column KK of T, larft forward/columnwise: T[c][KK] = -tau_KK sum_{m < KK} T[c][m] (v_m^T v_KK) for c < KK.  Lane c
+// reads row c of T from LDS (entries m < KK, written by earlier steps) and takes (v_m^T v_KK) / inv_KK = vg of
+// lane-column m through the DPP operand of the FMA -- one instruction per term, no broadcast registers.  In two halves
+// so that at most eight row entries are in registers at a time.
+template <int M0, int M1>
 struct TColumn {
-    static __device__ __forceinline__ double dot(const double (&Trow)[16], const double vg) {
-        return fma(Trow[M0], row_bcast<M0>(vg), TColumn<M0 + 1, KK>::dot(Trow, vg));
+    static __device__ __forceinline__ void load(double (&tr)[8], const double *__restrict__ Trow_lds) {
+        tr[M0 & 7] = Trow_lds[M0];
+        TColumn<M0 + 1, M1>::load(tr, Trow_lds);
+    }
+    static __device__ __forceinline__ void dot(double &acc0, double &acc1, const double (&tr)[8], const double vg) {
+        if constexpr (M0 & 1) fmac_bcast<M0>(acc1, vg, tr[M0 & 7]);
+        else fmac_bcast<M0>(acc0, vg, tr[M0 & 7]);
+        TColumn<M0 + 1, M1>::dot(acc0, acc1, tr, vg);
     }
 };
-template <int KK>
-struct TColumn<KK, KK> {
-    static __device__ __forceinline__ double dot(const double (&)[16], const double) { return 0.0; }
+template <int M1>
+struct TColumn<M1, M1> {
+    static __device__ __forceinline__ void load(double (&)[8], const double *__restrict__) {}
+    static __device__ __forceinline__ void dot(double &, double &, const double (&)[8], const double) {}
 };
 
+#ifdef FIGH_WY_LDSRED
+#define FIGH_WY_REDUCE(red, lane, x) allreduce_rowgroups_lds(red, lane, x)
+#else
+#define FIGH_WY_REDUCE(red, lane, x) allreduce_rowgroups(x)
+#endif
+
 // One column step of a panel.  X = the panel's chunk (lane (g, c): rows 16 rc + 4 r + g of column c, i = 4 rc + r),
-// Rl = the 16 x 16 diagonal block in wave-private LDS (row-major), Trow = row c of T, myinv = 1 / (alpha - beta) of
-// reflector c.  Columns c < KK are finished reflectors and stay frozen (they are V, up to the scaling by myinv).
+// Rl = the 16 x 16 diagonal block in wave-private LDS (row-major), Tl = the T factor being built (LDS, zero-filled),
+// myinv = 1 / (alpha - beta) of reflector c (0 until column c has been factored).  Columns c < KK are finished
+// reflectors and stay frozen (they are V, up to the scaling by myinv).
 template <int KK, int RPL>
-__device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double (&Trow)[16], double &myinv,
-                                              double *__restrict__ Rl, double *__restrict__ red, const int lane,
+__device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, double *__restrict__ Rl,
+                                              double *__restrict__ Tl, double *__restrict__ red, const int lane,
                                               const int c) {
     double rk = Rl[KK * 16 + c];  // row KK of the diagonal block: requested before the dot products
+    constexpr int KH = KK < 8 ? KK : 8;
+    double tr[8];
+    TColumn<0, KH>::load(tr, Tl + c * kLdt);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
     for (int i = 0; i < RPL; i += 4) {
@@ -75,79 +110,85 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double (&Trow)[1
         fmac_bcast<KK>(s2, X[i + 2], X[i + 2]);
         fmac_bcast<KK>(s3, X[i + 3], X[i + 3]);
     }
-    const double d = allreduce_rowgroups_lds(red, lane, (s0 + s1) + (s2 + s3));  // x^T X[:, c], all row groups
+    const double d = FIGH_WY_REDUCE(red, lane, (s0 + s1) + (s2 + s3));  // x^T X[:, c], identical in all row groups
     asm volatile("" : "+v"(rk));
     const double sigma = row_bcast<KK>(d);
     const double alpha = row_bcast<KK>(rk);
     if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
-    // column KK of T, the part that does not depend on this step's scalars: sum_m T[c][m] (x_m^T x_KK) inv_m
-    const double vg = (c < KK) ? d * myinv : 0.0;
-    const double acc = TColumn<0, KK>::dot(Trow, vg);
+    // (x_m^T x_KK) inv_m in lane-column m < KK, zero elsewhere (myinv is still zero for the columns not yet factored)
+    double vg = d * myinv;
+    asm volatile("s_nop 1" : "+v"(vg));  // VALU write -> DPP read of vg below: 2 wait states
+    double acc0 = 0.0, acc1 = 0.0;
+    TColumn<0, KH>::dot(acc0, acc1, tr, vg);
+    if constexpr (KK > 8) {
+        TColumn<8, KK>::load(tr, Tl + c * kLdt);
+        TColumn<8, KK>::dot(acc0, acc1, tr, vg);
+    }
     double inv, tfac;
     householder_scalars(alpha, sigma, inv, tfac);
-    // w_c = tau (R_kc + v^T X_c) for c >= KK; the pivot lane gets w = alpha - beta, i.e. R_kk = alpha - w = beta
+    // w_c = tau (R_kc + v^T X_c); the pivot lane gets w = alpha - beta, i.e. R_kk = alpha - w = beta
+    // (frozen columns c < KK: w = 0; their row entry rk is a structural zero of the diagonal block and stays one)
     const double wj = (c >= KK) ? (rk + d * inv) * tfac : 0.0;
-    const double ncj = (c > KK) ? -wj * inv : 0.0;
+    const double ncj = (c == KK) ? 0.0 : -wj * inv;
 #pragma unroll
     for (int i = 0; i < RPL; ++i) fmac_bcast<KK>(X[i], X[i], ncj);
-    if (lane < 16 && c >= KK) Rl[KK * 16 + c] = rk - wj;
-    Trow[KK] = (c < KK) ? -tfac * inv * acc : (c == KK ? tfac : 0.0);
-    if (c == KK) myinv = inv;
+    // row KK of the block and column KK of T are written by the whole first row group, no per-step lane masks: the
+    // sum of T's row entries is zero by itself for c >= KK (T is upper triangular, vg is zero there)
+    if (lane < 16) {
+        Rl[KK * 16 + c] = rk - wj;
+        Tl[c * kLdt + KK] = fma(-tfac * inv, acc0 + acc1, (c == KK) ? tfac : 0.0);
+    }
+    myinv = (c == KK) ? inv : myinv;
     // the next step reads X through DPP operands of inline asm, which the hazard recognizer cannot see: nothing of it
     // may be scheduled in between this step's updates (a VALU write needs 2 wait states before a DPP read)
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Factor one panel: on return Rl holds the new diagonal block, Vl (M x kLdv) the reflectors V = X diag(inv), Tl (16 x 16,
-// row-major) the T factor.
+// Factor one panel: on return Rl holds the new diagonal block, Vl (M x kLdv) the reflectors V = X diag(inv), Tl (16 x
+// kLdt, row-major) the T factor.
 template <int RPL>
 __device__ __forceinline__ void wy_factor_panel(double (&X)[RPL], double *__restrict__ Rl, double *__restrict__ red,
                                                 double *__restrict__ Vl, double *__restrict__ Tl, const int lane,
                                                 const int c, const int g) {
-    double Trow[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) Trow[m] = 0.0;
     double myinv = 0.0;
-    // X may still be in flight from the matrix pipe (the chunk update just before), and its first readers are DPP
-    // operands of inline asm: the required wait states (MFMA write -> VALU read, VALU write -> DPP read) are not
-    // inserted by the compiler for asm, so they are spelled out once per panel
+#pragma unroll
+    for (int e = lane; e < 16 * kLdt; e += 64) Tl[e] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // X may still be in flight from the matrix pipe or from LDS, and its first readers are DPP operands of inline asm:
+    // the required wait states (VALU write -> DPP read) are not inserted by the compiler for asm
 #pragma unroll
     for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(X[i]));
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    wy_panel_step<0, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<1, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<2, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<3, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<4, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<5, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<6, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<7, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<8, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<9, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<10, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<11, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<12, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<13, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<14, RPL>(X, Trow, myinv, Rl, red, lane, c);
-    wy_panel_step<15, RPL>(X, Trow, myinv, Rl, red, lane, c);
+    wy_panel_step<0, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<1, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<2, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<3, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<4, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<5, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<6, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<7, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<8, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<9, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<10, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<11, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<12, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<13, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<14, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<15, RPL>(X, myinv, Rl, Tl, red, lane, c);
 #pragma unroll
     for (int i = 0; i < RPL; ++i) Vl[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c] = X[i] * myinv;
-    if (g == 0) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) Tl[c * 16 + m] = Trow[m];
-    }
 }
 
 // Apply the panel's block reflector to one trailing chunk B (NRC row chunks of 16 x 16, C/D layout) and to its block of
-// the triangle (Rblock: element lane + 64 r = row g + 4 r, column c).
+// the triangle (Rpt = the block's current content, element lane + 64 r = row g + 4 r, column c; the new content goes
+// to Rblock).
 template <int NRC>
 __device__ __forceinline__ void wy_update_chunk(f64x4 (&B)[NRC], const double *__restrict__ Vl,
-                                                const double *__restrict__ Tl, double *__restrict__ Rblock, const int lane,
-                                                const int c, const int g) {
-    f64x4 Rpt;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Rpt[r] = Rblock[lane + 64 * r];
+                                                const double *__restrict__ Tl, const f64x4 Rpt,
+                                                double *__restrict__ Rblock, const int lane, const int c, const int g) {
     f64x4 G0 = {0.0, 0.0, 0.0, 0.0}, G1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int rc = 0; rc < NRC; ++rc) {
@@ -158,30 +199,42 @@ __device__ __forceinline__ void wy_update_chunk(f64x4 (&B)[NRC], const double *_
         G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * rc + 12 + g) * kLdv + c], B[rc][3], G1, 0, 0, 0);
     }
     const f64x4 G = (G0 + G1) + Rpt;  // G[r] = row g + 4 r of R_p,cc + V^T B
-    f64x4 Wm = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 4; ++r)  // A[i = c][k = g + 4 r] = T[g + 4 r][c] (= T^T), B[k][j = c] = G[g + 4 r][c]
-        Wm = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 4 * r) * 16 + c], G[r], Wm, 0, 0, 0);
+    // Wm = T^T G: A[i = c][k = g + 4 r] = T[g + 4 r][c], B[k][j = c] = G[g + 4 r][c]; two accumulators
+    const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    f64x4 W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 0) * kLdt + c], G[0], zero, 0, 0, 0);
+    f64x4 W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 4) * kLdt + c], G[1], zero, 0, 0, 0);
+    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 8) * kLdt + c], G[2], W0, 0, 0, 0);
+    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 12) * kLdt + c], G[3], W1, 0, 0, 0);
+    const f64x4 Wm = W0 + W1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Rblock[lane + 64 * r] = Rpt[r] - Wm[r];
     const f64x4 Wn = -Wm;
+    // B -= V Wm: A[i = c][k = g + 4 s] = V[row 16 rc + c][g + 4 s], B[k][j = c] = -Wm[g + 4 s][c]; the NRC row chunks
+    // are independent accumulators, so consecutive MFMAs never wait for each other
 #pragma unroll
-    for (int rc = 0; rc < NRC; ++rc)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)  // A[i = c][k = g + 4 s] = V[row 16 rc + c][g + 4 s], B[k][j = c] = -Wm[g + 4 s][c]
+        for (int rc = 0; rc < NRC; ++rc)
             B[rc] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * rc + c) * kLdv + g + 4 * s], Wn[s], B[rc], 0, 0, 0);
 }
 
-template <int NW, int CPW, int NRC>
-__global__ __launch_bounds__(64 * NW, 2) void tsqr_wy_kernel(const double *__restrict__ W, const long rows,
-                                                             const long ldw, const int *__restrict__ col_idx,
-                                                             const int n, const double *__restrict__ tau,
-                                                             const double *__restrict__ blkw, const long rows_per_blk,
-                                                             double *__restrict__ Rblk, double *__restrict__ Rout,
-                                                             const int nc) {
+// WPE = waves per SIMD the kernel is built for.  WPE = 1: the wave may use the whole register file of its SIMD (256
+// VGPRs + 256 AGPRs), and -- the point -- no other wave shares its FP64 pipe: an f64 MFMA holds the pipe for 64 cycles
+// and cannot be pre-empted, so a panel's dependent VALU chain next to a wave that streams MFMAs runs 2-3x slower
+// (measured: 1250 instead of ~600 cycles per column step).  4 / NW workgroups are resident per CU then, one wave on
+// each SIMD, each workgroup an independent chain of panels.
+template <int NW, int CPW, int NRC, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__restrict__ W, const long rows,
+                                                               const long ldw, const int *__restrict__ col_idx,
+                                                               const int n, const double *__restrict__ tau,
+                                                               const double *__restrict__ blkw, const long rows_per_blk,
+                                                               double *__restrict__ Rblk, double *__restrict__ Rout,
+                                                               const int nc, long long *__restrict__ prof) {
     static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
-    constexpr int RPL = 4 * NRC, M = 16 * NRC, VBUF = M * kLdv + 256;
-    __shared__ double vt[2][VBUF];      // ping-pong: V (M x kLdv) followed by T (16 x 16)
+    FIGH_PROF_DECL
+    if constexpr (WPE == 1) asm volatile("" ::: "a255");  // the allocation covers the SIMD: never two waves on one
+    constexpr int RPL = 4 * NRC, M = 16 * NRC, VBUF = M * kLdv + 16 * kLdt;
+    __shared__ double vt[2][VBUF];      // ping-pong: V (M x kLdv) followed by T (16 x kLdt)
     __shared__ double rpp[NW][256];     // the diagonal block of the panel a wave is factoring (wave-private)
     __shared__ double redbuf[NW][64];   // cross-row-group sums (wave-private)
     __shared__ int fnz[2][NW];
@@ -207,10 +260,10 @@ __global__ __launch_bounds__(64 * NW, 2) void tsqr_wy_kernel(const double *__res
     }
 
     // per-lane column sources.  Full tiles are read through a wave-uniform row base (SGPR pair) + a 32-bit per-lane
-    // element offset g*ldw + column (the host side guarantees ldw < 2^24); tau is column n; everything beyond is a dead
-    // lane-column whose registers stay exactly zero for the whole kernel (zero data, zero triangle entries).
+    // byte offset (the host side guarantees ldw < 2^24); tau is column n; everything beyond is a dead lane-column whose
+    // registers stay exactly zero for the whole kernel (zero data, zero triangle entries).
     bool wlive[CPW], tlive[CPW];
-    unsigned boff[CPW];  // BYTE offset of (row g, my column) from the row base: unsigned 32 bits = the saddr + voffset form
+    unsigned boff[CPW];
     int wcol[CPW];
 #pragma unroll
     for (int s = 0; s < CPW; ++s) {
@@ -221,6 +274,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tsqr_wy_kernel(const double *__res
         boff[s] = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)wcol[s]);
     }
     const unsigned toff = 8u * (unsigned)g;
+    const unsigned ldw8 = 8u * (unsigned)ldw;  // bytes per row (the host side guarantees 64 * ldw * 8 < 2^32)
 
     f64x4 T[CPW][NRC];
 #pragma unroll
@@ -231,19 +285,50 @@ __global__ __launch_bounds__(64 * NW, 2) void tsqr_wy_kernel(const double *__res
 #pragma unroll
     for (int s = 0; s < CPW; ++s) pf[s] = false;
 
-    // loads of one chunk of a FULL tile at row r0_: RPL independent requests per lane, dead lanes keep their zeros
+    // loads of one chunk of a FULL tile at row r0_: RPL independent requests per lane, dead lanes keep their zeros.
+    // Buffer loads: the row base goes into an SGPR resource descriptor, the row offsets inside the tile into SGPR
+    // soffsets, and the lane contributes ONE 32-bit byte offset -- no 64-bit per-lane pointers (the compiler spilled
+    // those, and the reload's s_waitcnt vmcnt(0) then also waited for the triangle stores just issued: ~3000 cycles on
+    // the critical path of every panel).
 #define FIGH_WY_LOAD(s, r0_)                                                                                      \
     do {                                                                                                          \
         if (wlive[s]) {                                                                                           \
-            _Pragma("unroll") for (int i = 0; i < RPL; ++i)                                                       \
-                T[s][i >> 2][i & 3] = *reinterpret_cast<const double *>(                                          \
-                    reinterpret_cast<const char *>(W + ((r0_) + 16 * (i >> 2) + 4 * (i & 3)) * ldw) + boff[s]);   \
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
+                const_cast<double *>(W + (r0_) * ldw), (short)0, 0x7fffffff, 0x00020000);                         \
+            _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                     \
+                const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(                                            \
+                    rs_, boff[s], (unsigned)(16 * (i >> 2) + 4 * (i & 3)) * ldw8, 0);                             \
+                T[s][i >> 2][i & 3] = __hiloint2double((int)v_[1], (int)v_[0]);                                   \
+            }                                                                                                     \
         }                                                                                                         \
         if (tlive[s]) {                                                                                           \
-            _Pragma("unroll") for (int i = 0; i < RPL; ++i)                                                       \
-                T[s][i >> 2][i & 3] = *reinterpret_cast<const double *>(                                          \
-                    reinterpret_cast<const char *>(tau + (r0_) + 16 * (i >> 2) + 4 * (i & 3)) + toff);            \
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
+                const_cast<double *>(tau + (r0_)), (short)0, 0x7fffffff, 0x00020000);                             \
+            _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                     \
+                const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(                                            \
+                    rs_, toff, 8u * (unsigned)(16 * (i >> 2) + 4 * (i & 3)), 0);                                  \
+                T[s][i >> 2][i & 3] = __hiloint2double((int)v_[1], (int)v_[0]);                                   \
+            }                                                                                                     \
         }                                                                                                         \
+    } while (0)
+    // run BODY(k) for the slot k == sel (a wave-uniform run-time value): a real switch -- with a chain of unrolled
+    // `if (s == sel)` the register allocator keeps two copies of every slot alive (836 spills at CPW = 6)
+#define FIGH_WY_SLOT_CASE(k, BODY) \
+    case k:                        \
+        if constexpr (k < CPW) { constexpr int S_ = k < CPW ? k : 0; BODY(S_); } \
+        break;
+#define FIGH_WY_SLOT_SWITCH(sel, BODY)                                                                             \
+    switch (sel) {                                                                                                 \
+        FIGH_WY_SLOT_CASE(0, BODY) FIGH_WY_SLOT_CASE(1, BODY) FIGH_WY_SLOT_CASE(2, BODY) FIGH_WY_SLOT_CASE(3, BODY)  \
+        FIGH_WY_SLOT_CASE(4, BODY) FIGH_WY_SLOT_CASE(5, BODY) FIGH_WY_SLOT_CASE(6, BODY) FIGH_WY_SLOT_CASE(7, BODY)  \
+        FIGH_WY_SLOT_CASE(8, BODY) FIGH_WY_SLOT_CASE(9, BODY) FIGH_WY_SLOT_CASE(10, BODY) FIGH_WY_SLOT_CASE(11, BODY) \
+        default: break;                                                                                            \
+    }
+#define FIGH_WY_WAVE_SYNC()                                  \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
     const long ntiles = (rows + M - 1) / M;
@@ -291,102 +376,143 @@ __global__ __launch_bounds__(64 * NW, 2) void tsqr_wy_kernel(const double *__res
             if (m16) myfirst = 16 * (wave + NW * s) + __ffs((int)m16) - 1;
             pf[s] = false;
         }
-        if (lane == 0) fnz[parity][wave] = myfirst;
-        __syncthreads();
-        int first_nz = fnz[parity][0];
+        int p0;
+        if constexpr (NW > 1) {
+            if (lane == 0) fnz[parity][wave] = myfirst;
+            __syncthreads();
+            int first_nz = fnz[parity][0];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) first_nz = min(first_nz, fnz[parity][w]);
-        const int p0 = __builtin_amdgcn_readfirstlane(first_nz) >> 4;
+            for (int w = 1; w < NW; ++w) first_nz = min(first_nz, fnz[parity][w]);
+            p0 = __builtin_amdgcn_readfirstlane(first_nz) >> 4;
+        } else {
+            p0 = __builtin_amdgcn_readfirstlane(myfirst) >> 4;
+        }
+        FIGH_PROF_ADD(1);
         if (p0 >= nch) continue;  // the tile is zero
 
-        // ---- the first panel of the tile has nobody to overlap with
+        // ---- the first panel of the tile has nobody to overlap with.  The slot-specific part (a real switch over the
+        // wave-uniform slot index) only stages the chunk in the LDS buffer that will receive V and refills the retired
+        // registers with the coming tile's chunk; the panel code itself is common and takes X from LDS, so no register
+        // value flows from a run-time-selected slot into it (that kind of merge made the allocator keep two copies of every
+        // slot: hundreds of spills at CPW >= 6).
         if (wave == (p0 & (NW - 1))) {
+            __builtin_amdgcn_s_setprio(3);
             const int so = p0 / NW;
-            double X[RPL];
-#pragma unroll
-            for (int s = 0; s < CPW; ++s)
-                if (s == so) {
-#pragma unroll
-                    for (int i = 0; i < RPL; ++i) X[i] = T[s][i >> 2][i & 3];
-                }
+            double *Vn = vt[p0 & 1];
+            long rn = r0n;
+            asm volatile("" : "+s"(rn));  // opaque: the row addresses of the refill must not be hoisted out of the loops
+#define FIGH_WY_BODY(S_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < RPL; ++i)                                                    \
+        Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c] = T[S_][i >> 2][i & 3];                        \
+    if (next_full) {                                                                                   \
+        FIGH_WY_LOAD(S_, rn);                                                                          \
+        pf[S_] = true;                                                                                 \
+    }
+            FIGH_WY_SLOT_SWITCH(so, FIGH_WY_BODY)
+#undef FIGH_WY_BODY
             double *bpp = block(p0, p0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = bpp[lane + 64 * r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double *Vn = vt[p0 & 1];
+            FIGH_WY_WAVE_SYNC();
+            double X[RPL];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) X[i] = Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c];
             wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            FIGH_WY_WAVE_SYNC();
 #pragma unroll
             for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
-            if (next_full) {  // the chunk is retired: its registers take the coming tile's chunk
-                long rn = r0n;
-                asm volatile("" : "+s"(rn));  // opaque: the 16 row addresses must not be hoisted out of the phase loop
-#pragma unroll
-                for (int s = 0; s < CPW; ++s)
-                    if (s == so) {
-                        FIGH_WY_LOAD(s, rn);
-                        pf[s] = true;
-                    }
-            }
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
+        FIGH_PROF_ADD(2);
 
-        // ---- phase p: apply panel p to the trailing chunks; the owner of chunk p + 1 factors panel p + 1 meanwhile
+        // ---- phase p: apply panel p to the trailing chunks; the owner of chunk p + 1 factors panel p + 1 meanwhile.
+        // The two blocks of the triangle that the owner's critical path starts with -- (p, p+1) for the chunk update,
+        // (p+1, p+1) for the panel -- were requested one phase earlier (rp_next, rq_next).
+        f64x4 rp_next = {0.0, 0.0, 0.0, 0.0}, rq_next = {0.0, 0.0, 0.0, 0.0};
+        bool have_next = false;
         for (int p = p0; p + 1 < nch; ++p) {
             const double *Vl = vt[p & 1];
             const double *Tl = Vl + M * kLdv;
             const int pn = p + 1;
-            if (wave == (pn & (NW - 1))) {
+            const bool own_pn = wave == (pn & (NW - 1));
+            f64x4 rp = rp_next, rq = rq_next;
+            const bool have = have_next;
+            have_next = false;
+            if (pn + 1 < nch && wave == ((pn + 1) & (NW - 1))) {  // owner of the phase after this one
+                const double *b1 = block(pn, pn + 1), *b2 = block(pn + 1, pn + 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rp_next[r] = b1[lane + 64 * r];
+                    rq_next[r] = b2[lane + 64 * r];
+                }
+                have_next = true;
+            }
+            if (own_pn) {
+                // this wave is the critical path of the workgroup until panel p + 1 is published: it wins the issue
+                // arbitration against the waves it shares the SIMD with
+                __builtin_amdgcn_s_setprio(3);
                 const int sn = pn / NW;
                 double *bpp = block(pn, pn);
-                f64x4 rq;  // diagonal block of the coming panel: requested before the MFMA chain of the chunk update
+                if (!have) {
+                    const double *b1 = block(p, pn);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rq[r] = bpp[lane + 64 * r];
-                double X[RPL];
-#pragma unroll
-                for (int s = 0; s < CPW; ++s)
-                    if (s == sn) {
-                        wy_update_chunk<NRC>(T[s], Vl, Tl, block(p, pn), lane, c, g);
-#pragma unroll
-                        for (int i = 0; i < RPL; ++i) X[i] = T[s][i >> 2][i & 3];
+                    for (int r = 0; r < 4; ++r) {
+                        rp[r] = b1[lane + 64 * r];
+                        rq[r] = bpp[lane + 64 * r];
                     }
+                }
+                double *bpn = block(p, pn);
+                double *Vn = vt[pn & 1];
+                long rn = r0n;
+                asm volatile("" : "+s"(rn));
+#define FIGH_WY_BODY(S_)                                                                               \
+    wy_update_chunk<NRC>(T[S_], Vl, Tl, rp, bpn, lane, c, g);                                           \
+    FIGH_PROF_ADD(7);                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < RPL; ++i)                                                    \
+        Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c] = T[S_][i >> 2][i & 3];                        \
+    if (next_full) {                                                                                   \
+        FIGH_WY_LOAD(S_, rn);                                                                          \
+        pf[S_] = true;                                                                                 \
+    }
+                FIGH_WY_SLOT_SWITCH(sn, FIGH_WY_BODY)
+#undef FIGH_WY_BODY
+                FIGH_PROF_ADD(3);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = rq[r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                double *Vn = vt[pn & 1];
+                FIGH_WY_WAVE_SYNC();
+                double X[RPL];
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) X[i] = Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c];
                 wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                FIGH_WY_WAVE_SYNC();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
-                if (next_full) {
-                    long rn = r0n;
-                    asm volatile("" : "+s"(rn));  // (as above: keeps 32 VGPRs of loop-invariant addresses per chunk away)
-#pragma unroll
-                    for (int s = 0; s < CPW; ++s)
-                        if (s == sn) {
-                            FIGH_WY_LOAD(s, rn);
-                            pf[s] = true;
-                        }
-                }
+                __builtin_amdgcn_s_setprio(0);
+                FIGH_PROF_ADD(4);
             }
 #pragma unroll
             for (int s = 0; s < CPW; ++s) {
                 const int cc = wave + NW * s;
-                if (cc > pn && cc < nch) wy_update_chunk<NRC>(T[s], Vl, Tl, block(p, cc), lane, c, g);
+                if (cc > pn && cc < nch) {
+                    double *b = block(p, cc);
+                    f64x4 rb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rb[r] = b[lane + 64 * r];
+                    wy_update_chunk<NRC>(T[s], Vl, Tl, rb, b, lane, c, g);
+                }
                 __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: hoisting the next chunk's operands costs registers
             }
+            FIGH_PROF_ADD(5);
             __syncthreads();
+            FIGH_PROF_ADD(6);
         }
     }
 #undef FIGH_WY_LOAD
+#undef FIGH_WY_WAVE_SYNC
+#undef FIGH_WY_SLOT_SWITCH
+#undef FIGH_WY_SLOT_CASE
+    FIGH_PROF_STORE(prof, wave, NW);
 
     // ---- write this wave's columns of the nc x nc row-major triangle (zeros below the diagonal)
     double *Ro = Rout + (long)blockIdx.x * nc * nc;
@@ -407,12 +533,13 @@ __global__ __launch_bounds__(64 * NW, 2) void tsqr_wy_kernel(const double *__res
     }
 }
 
-template <int NW, int CPW, int NRC>
+template <int NW, int CPW, int NRC, int WPE>
 int wy_occupancy() {  // resident workgroups per CU (registers and LDS decide)
     static int nb = 0;
     if (!nb) {
         int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, tsqr_wy_kernel<NW, CPW, NRC>, 64 * NW, 0) != hipSuccess || v < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, tsqr_wy_kernel<NW, CPW, NRC, WPE>, 64 * NW, 0) != hipSuccess ||
+            v < 1)
             v = 1;
         nb = v;
     }
@@ -420,46 +547,45 @@ int wy_occupancy() {  // resident workgroups per CU (registers and LDS decide)
 }
 
 struct WyConfig {
-    int nw, cpw, nrc;
+    int nw, cpw, nrc, wpe;
 };
 
-// Geometry by column count.  Four waves per workgroup while a wave's share of the tile (CPW chunk slots of 32 registers)
-// leaves room for the panel state in 256 registers -- two workgroups per CU then run independent panel chains that hide
-// each other's latency; eight waves beyond.
+// Geometry by column count (one wave per SIMD throughout, see tsqr_wy_kernel): as few waves per workgroup -- as many
+// independent panel chains per CU -- as the register file allows for the workgroup's tile.
 WyConfig wy_config(const int nc) {
     const int nch = (nc + 15) >> 4;
 #ifdef FIGH_ABLATION
-    if (const char *e = getenv("FIGH_WY_CFG")) {  // "nw,cpw,nrc" (ablation build only)
-        WyConfig cfg{0, 0, 0};
-        if (sscanf(e, "%d,%d,%d", &cfg.nw, &cfg.cpw, &cfg.nrc) == 3 && cfg.nw * cfg.cpw >= nch) return cfg;
+    if (const char *e = getenv("FIGH_WY_CFG")) {  // "nw,cpw,nrc,wpe" (ablation build only)
+        WyConfig cfg{0, 0, 0, 0};
+        if (sscanf(e, "%d,%d,%d,%d", &cfg.nw, &cfg.cpw, &cfg.nrc, &cfg.wpe) == 4 && cfg.nw * cfg.cpw >= nch) return cfg;
     }
 #endif
-    if (nch <= 8) return {4, 2, 4};
-    if (nch <= 12) return {4, 3, 4};
-    if (nch <= 16) return {8, 2, 4};
-    if (nch <= 24) return {8, 3, 4};
-    return {8, 4, 4};
+    if (nch <= 12) return {4, 3, 4, 2};
+    if (nch <= 16) return {4, 4, 4, 2};
+    if (nch <= 24) return {8, 3, 4, 2};
+    return {8, 4, 4, 2};
 }
 
 template <class F>
 bool wy_dispatch(const WyConfig cfg, F &&f) {
-#define FIGH_WY_CASE(NW_, CPW_, NRC_)                                                              \
-    if (cfg.nw == NW_ && cfg.cpw == CPW_ && cfg.nrc == NRC_) {                                     \
+#define FIGH_WY_CASE(NW_, CPW_, NRC_, WPE_)                                                        \
+    if (cfg.nw == NW_ && cfg.cpw == CPW_ && cfg.nrc == NRC_ && cfg.wpe == WPE_) {                  \
         f(std::integral_constant<int, NW_>{}, std::integral_constant<int, CPW_>{},                 \
-          std::integral_constant<int, NRC_>{});                                                    \
+          std::integral_constant<int, NRC_>{}, std::integral_constant<int, WPE_>{});               \
         return true;                                                                               \
     }
-    FIGH_WY_CASE(4, 2, 4)
-    FIGH_WY_CASE(4, 3, 4)
-    FIGH_WY_CASE(8, 2, 4)
-    FIGH_WY_CASE(8, 3, 4)
-    FIGH_WY_CASE(8, 4, 4)
+    FIGH_WY_CASE(4, 3, 4, 2)
+    FIGH_WY_CASE(4, 4, 4, 2)
+    FIGH_WY_CASE(8, 3, 4, 2)
+    FIGH_WY_CASE(8, 4, 4, 2)
 #ifdef FIGH_ABLATION
-    FIGH_WY_CASE(4, 4, 4)
-    FIGH_WY_CASE(4, 4, 2)
-    FIGH_WY_CASE(4, 6, 2)
-    FIGH_WY_CASE(4, 8, 2)
-    FIGH_WY_CASE(8, 3, 2)
+    FIGH_WY_CASE(8, 2, 4, 3)
+    FIGH_WY_CASE(8, 2, 4, 2)
+    FIGH_WY_CASE(4, 3, 4, 1)
+    FIGH_WY_CASE(4, 6, 4, 1)
+    FIGH_WY_CASE(8, 3, 2, 4)
+    FIGH_WY_CASE(8, 3, 2, 3)
+    FIGH_WY_CASE(8, 4, 2, 3)
 #endif
 #undef FIGH_WY_CASE
     return false;
@@ -470,8 +596,8 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
 // persistent workgroups the wide kernel wants for nc columns (one private triangle each)
 long tsqr_wide_workgroups(const int nc, const int cus) {
     int occ = 1;
-    wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC) {
-        occ = wy_occupancy<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value>();
+    wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE) {
+        occ = wy_occupancy<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value, decltype(WPE)::value>();
     });
     return (long)cus * occ;
 }
@@ -483,16 +609,41 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
     const size_t blk_bytes = sizeof(double) * 256 * ((size_t)nch * (nch + 1) / 2) * (size_t)nwg;
     double *Rblk = static_cast<double *>(workspace(blk_bytes, 13));
     if (!Rblk) return FIGH_ERR_ALLOC;
-    const bool ok = wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC) {
-        hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value>),
+    long long *prof = nullptr;
+#ifdef FIGH_ABLATION
+    const WyConfig pcfg = wy_config(nc);
+    static const bool want_prof = getenv("FIGH_WY_PROF") != nullptr;
+    if (want_prof && rows >= 65536) {
+        prof = static_cast<long long *>(workspace(sizeof(long long) * 12 * nwg * pcfg.nw, 6));
+        if (!prof) return FIGH_ERR_ALLOC;
+    }
+#endif
+    const bool ok = wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE) {
+        hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value, decltype(WPE)::value>),
                            dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, stream(), W, rows, ldw, col_idx, n, tau,
-                           d_blkw, rows_per_blk, Rblk, Rws_out, nc);
+                           d_blkw, rows_per_blk, Rblk, Rws_out, nc, prof);
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");
         return FIGH_ERR_UNSUPPORTED;
     }
     FIGH_HIP(hipGetLastError());
+#ifdef FIGH_ABLATION
+    if (prof) {
+        const long nwv = nwg * pcfg.nw;
+        std::vector<long long> h(12 * nwv);
+        FIGH_HIP(hipMemcpyAsync(h.data(), prof, sizeof(long long) * 12 * nwv, hipMemcpyDeviceToHost, stream()));
+        FIGH_HIP(hipStreamSynchronize(stream()));
+        double acc[12] = {0};
+        for (long w = 0; w < nwv; ++w)
+            for (int k = 0; k < 12; ++k) acc[k] += (double)h[12 * w + k];
+        const long ntiles = (rows + 16 * pcfg.nrc - 1) / (16 * pcfg.nrc);
+        fprintf(stderr, "[wy prof] cfg %d,%d,%d,%d nc %d wgs %ld (occupancy %ld/CU) tiles/wg %.1f | ticks per wave: kernel %.0f = top %.0f + "
+                        "first panel %.0f + la-update %.0f + la-stage %.0f + la-panel %.0f + updates %.0f + barrier %.0f\n",
+                pcfg.nw, pcfg.cpw, pcfg.nrc, pcfg.wpe, nc, nwg, tsqr_wide_workgroups(nc, 1), (double)ntiles / nwg, acc[0] / nwv, acc[1] / nwv,
+                acc[2] / nwv, acc[7] / nwv, acc[3] / nwv, acc[4] / nwv, acc[5] / nwv, acc[6] / nwv);
+    }
+#endif
     return FIGH_OK;
 }
 
