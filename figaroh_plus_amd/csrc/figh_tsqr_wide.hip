@@ -189,40 +189,61 @@ template <int NRC>
 __device__ __forceinline__ void wy_update_chunk(f64x4 (&B)[NRC], const double *__restrict__ Vl,
                                                 const double *__restrict__ Tl, const f64x4 Rpt,
                                                 double *__restrict__ Rblock, const int lane, const int c, const int g) {
+    // operands of the first two stages: requested together, up front (left to itself the compiler fetches them in pairs
+    // right in front of their MFMAs and the matrix pipe waits ~60 cycles per pair for the LDS round trip)
+    double vc[4 * NRC], tt[4];
+#pragma unroll
+    for (int i = 0; i < 4 * NRC; ++i) vc[i] = Vl[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tt[r] = Tl[(g + 4 * r) * kLdt + c];
     f64x4 G0 = {0.0, 0.0, 0.0, 0.0}, G1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int rc = 0; rc < NRC; ++rc) {
         // A[i = c][k = g] = V[row 16 rc + 4 r + g][c], B[k = g][j = c] = the tile entry of the same row: K-slice r
-        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * rc + 0 + g) * kLdv + c], B[rc][0], G0, 0, 0, 0);
-        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * rc + 4 + g) * kLdv + c], B[rc][1], G1, 0, 0, 0);
-        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * rc + 8 + g) * kLdv + c], B[rc][2], G0, 0, 0, 0);
-        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * rc + 12 + g) * kLdv + c], B[rc][3], G1, 0, 0, 0);
+        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 0], B[rc][0], G0, 0, 0, 0);
+        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 1], B[rc][1], G1, 0, 0, 0);
+        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 2], B[rc][2], G0, 0, 0, 0);
+        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 3], B[rc][3], G1, 0, 0, 0);
     }
+    // (three stages, fenced for the scheduler: hoisting the LDS operands of the last stage into the first costs 32
+    // registers and buys nothing)
+    __builtin_amdgcn_sched_barrier(0);
+    // operands of the last stage (V transposed): in flight while the first stage drains and the T stage runs
+    double vr[4][NRC];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rc = 0; rc < NRC; ++rc) vr[s][rc] = Vl[(16 * rc + c) * kLdv + g + 4 * s];
     const f64x4 G = (G0 + G1) + Rpt;  // G[r] = row g + 4 r of R_p,cc + V^T B
     // Wm = T^T G: A[i = c][k = g + 4 r] = T[g + 4 r][c], B[k][j = c] = G[g + 4 r][c]; two accumulators
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-    f64x4 W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 0) * kLdt + c], G[0], zero, 0, 0, 0);
-    f64x4 W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 4) * kLdt + c], G[1], zero, 0, 0, 0);
-    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 8) * kLdt + c], G[2], W0, 0, 0, 0);
-    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(g + 12) * kLdt + c], G[3], W1, 0, 0, 0);
+    f64x4 W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[0], G[0], zero, 0, 0, 0);
+    f64x4 W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[1], G[1], zero, 0, 0, 0);
+    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[2], G[2], W0, 0, 0, 0);
+    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[3], G[3], W1, 0, 0, 0);
     const f64x4 Wm = W0 + W1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Rblock[lane + 64 * r] = Rpt[r] - Wm[r];
     const f64x4 Wn = -Wm;
+    __builtin_amdgcn_sched_barrier(0);
     // B -= V Wm: A[i = c][k = g + 4 s] = V[row 16 rc + c][g + 4 s], B[k][j = c] = -Wm[g + 4 s][c]; the NRC row chunks
     // are independent accumulators, so consecutive MFMAs never wait for each other
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int rc = 0; rc < NRC; ++rc)
-            B[rc] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * rc + c) * kLdv + g + 4 * s], Wn[s], B[rc], 0, 0, 0);
+            B[rc] = __builtin_amdgcn_mfma_f64_16x16x4f64(vr[s][rc], Wn[s], B[rc], 0, 0, 0);
 }
 
-// WPE = waves per SIMD the kernel is built for.  WPE = 1: the wave may use the whole register file of its SIMD (256
-// VGPRs + 256 AGPRs), and -- the point -- no other wave shares its FP64 pipe: an f64 MFMA holds the pipe for 64 cycles
-// and cannot be pre-empted, so a panel's dependent VALU chain next to a wave that streams MFMAs runs 2-3x slower
-// (measured: 1250 instead of ~600 cycles per column step).  4 / NW workgroups are resident per CU then, one wave on
-// each SIMD, each workgroup an independent chain of panels.
+// WPE = waves per SIMD the kernel is built for (register budget 512 / WPE).
+//
+// Register queue.  A wave's CPW chunks live in a queue of register slots: F holds the wave's next chunk to become a panel
+// (chunk index `front`), Q[j] the chunk front + NW (j + 1).  When a chunk retires (its panel is factored, or it lies in
+// front of the tile's first non-zero column) the queue is ROTATED by register moves and the freed slot at the back is
+// refilled with the same chunk of the coming tile.  Every slot index in the code is therefore a compile-time constant;
+// the only run-time quantity is `front`.  (The obvious alternative -- fixed slots and a run-time slot index through a
+// switch or a chain of `if (s == sel)` -- makes the compiler route the selected slot through a shared register set
+// (64 v_mov per use) or keep two copies of every slot alive: hundreds of spills, LDS operands fetched one by one.)
 template <int NW, int CPW, int NRC, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__restrict__ W, const long rows,
                                                                const long ldw, const int *__restrict__ col_idx,
@@ -230,10 +251,11 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                                                                const double *__restrict__ blkw, const long rows_per_blk,
                                                                double *__restrict__ Rblk, double *__restrict__ Rout,
                                                                const int nc, long long *__restrict__ prof) {
-    static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
+    static_assert((NW & (NW - 1)) == 0 && NW >= 2, "NW must be a power of two >= 2");
+    static_assert(CPW >= 2, "at least two chunk slots per wave");
     FIGH_PROF_DECL
     if constexpr (WPE == 1) asm volatile("" ::: "a255");  // the allocation covers the SIMD: never two waves on one
-    constexpr int RPL = 4 * NRC, M = 16 * NRC, VBUF = M * kLdv + 16 * kLdt;
+    constexpr int RPL = 4 * NRC, M = 16 * NRC, VBUF = M * kLdv + 16 * kLdt, NQ = CPW - 1;
     __shared__ double vt[2][VBUF];      // ping-pong: V (M x kLdv) followed by T (16 x kLdt)
     __shared__ double rpp[NW][256];     // the diagonal block of the panel a wave is factoring (wave-private)
     __shared__ double redbuf[NW][64];   // cross-row-group sums (wave-private)
@@ -259,108 +281,116 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
             }
     }
 
-    // per-lane column sources.  Full tiles are read through a wave-uniform row base (SGPR pair) + a 32-bit per-lane
-    // byte offset (the host side guarantees ldw < 2^24); tau is column n; everything beyond is a dead lane-column whose
-    // registers stay exactly zero for the whole kernel (zero data, zero triangle entries).
-    bool wlive[CPW], tlive[CPW];
-    unsigned boff[CPW];
-    int wcol[CPW];
-#pragma unroll
-    for (int s = 0; s < CPW; ++s) {
+    // One queue slot: the tile chunk (C/D layout) and its per-lane column source.  Full tiles are read with buffer loads:
+    // row base in an SGPR resource descriptor, row offsets inside the tile in SGPR soffsets, ONE 32-bit byte offset per
+    // lane (boff; tau is column n and uses its own descriptor).  Lane-columns beyond the matrix are dead: their registers
+    // stay exactly zero for the whole kernel (zero data, zero triangle entries, and neither panel nor update changes a
+    // zero column).
+    struct Slot {
+        f64x4 t[NRC];
+        unsigned boff;
+        int wcol;
+        bool wlive, tlive;
+    };
+    Slot F, Q[NQ];
+    auto init_slot = [&](Slot &S, const int s) {
         const int col = 16 * (wave + NW * s) + c;
-        wlive[s] = col < n;
-        tlive[s] = col == n && tau != nullptr;
-        wcol[s] = wlive[s] ? (col_idx ? col_idx[col] : col) : 0;
-        boff[s] = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)wcol[s]);
-    }
+        S.wlive = col < n;
+        S.tlive = col == n && tau != nullptr;
+        S.wcol = S.wlive ? (col_idx ? col_idx[col] : col) : 0;
+        S.boff = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)S.wcol);
+#pragma unroll
+        for (int rc = 0; rc < NRC; ++rc) S.t[rc] = f64x4{0.0, 0.0, 0.0, 0.0};
+    };
+    init_slot(F, 0);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) init_slot(Q[j], j + 1);
     const unsigned toff = 8u * (unsigned)g;
     const unsigned ldw8 = 8u * (unsigned)ldw;  // bytes per row (the host side guarantees 64 * ldw * 8 < 2^32)
 
-    f64x4 T[CPW][NRC];
-#pragma unroll
-    for (int s = 0; s < CPW; ++s)
-#pragma unroll
-        for (int rc = 0; rc < NRC; ++rc) T[s][rc] = f64x4{0.0, 0.0, 0.0, 0.0};
-    bool pf[CPW];  // chunk registers already hold the data of the coming tile
-#pragma unroll
-    for (int s = 0; s < CPW; ++s) pf[s] = false;
-
-    // loads of one chunk of a FULL tile at row r0_: RPL independent requests per lane, dead lanes keep their zeros.
-    // Buffer loads: the row base goes into an SGPR resource descriptor, the row offsets inside the tile into SGPR
-    // soffsets, and the lane contributes ONE 32-bit byte offset -- no 64-bit per-lane pointers (the compiler spilled
-    // those, and the reload's s_waitcnt vmcnt(0) then also waited for the triangle stores just issued: ~3000 cycles on
-    // the critical path of every panel).
-#define FIGH_WY_LOAD(s, r0_)                                                                                      \
+    // requests for the chunk of slot S_ in the FULL tile at row r0_: RPL independent loads per lane
+#define FIGH_WY_LOAD(S_, r0_)                                                                                     \
     do {                                                                                                          \
-        if (wlive[s]) {                                                                                           \
+        if ((S_).wlive) {                                                                                         \
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
                 const_cast<double *>(W + (r0_) * ldw), (short)0, 0x7fffffff, 0x00020000);                         \
             _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                     \
                 const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(                                            \
-                    rs_, boff[s], (unsigned)(16 * (i >> 2) + 4 * (i & 3)) * ldw8, 0);                             \
-                T[s][i >> 2][i & 3] = __hiloint2double((int)v_[1], (int)v_[0]);                                   \
+                    rs_, (S_).boff, (unsigned)(16 * (i >> 2) + 4 * (i & 3)) * ldw8, 0);                           \
+                (S_).t[i >> 2][i & 3] = __hiloint2double((int)v_[1], (int)v_[0]);                                 \
             }                                                                                                     \
         }                                                                                                         \
-        if (tlive[s]) {                                                                                           \
+        if ((S_).tlive) {                                                                                         \
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
                 const_cast<double *>(tau + (r0_)), (short)0, 0x7fffffff, 0x00020000);                             \
             _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                     \
                 const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(                                            \
                     rs_, toff, 8u * (unsigned)(16 * (i >> 2) + 4 * (i & 3)), 0);                                  \
-                T[s][i >> 2][i & 3] = __hiloint2double((int)v_[1], (int)v_[0]);                                   \
+                (S_).t[i >> 2][i & 3] = __hiloint2double((int)v_[1], (int)v_[0]);                                 \
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
-    // run BODY(k) for the slot k == sel (a wave-uniform run-time value): a real switch -- with a chain of unrolled
-    // `if (s == sel)` the register allocator keeps two copies of every slot alive (836 spills at CPW = 6)
-#define FIGH_WY_SLOT_CASE(k, BODY) \
-    case k:                        \
-        if constexpr (k < CPW) { constexpr int S_ = k < CPW ? k : 0; BODY(S_); } \
-        break;
-#define FIGH_WY_SLOT_SWITCH(sel, BODY)                                                                             \
-    switch (sel) {                                                                                                 \
-        FIGH_WY_SLOT_CASE(0, BODY) FIGH_WY_SLOT_CASE(1, BODY) FIGH_WY_SLOT_CASE(2, BODY) FIGH_WY_SLOT_CASE(3, BODY)  \
-        FIGH_WY_SLOT_CASE(4, BODY) FIGH_WY_SLOT_CASE(5, BODY) FIGH_WY_SLOT_CASE(6, BODY) FIGH_WY_SLOT_CASE(7, BODY)  \
-        FIGH_WY_SLOT_CASE(8, BODY) FIGH_WY_SLOT_CASE(9, BODY) FIGH_WY_SLOT_CASE(10, BODY) FIGH_WY_SLOT_CASE(11, BODY) \
-        default: break;                                                                                            \
+    // the last, ragged tile: rows clamped, then masked
+#define FIGH_WY_LOAD_RAGGED(S_, r0_)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                             \
+        const long row_ = (r0_) + 16 * (i >> 2) + 4 * (i & 3) + g;                                                \
+        const long rowc_ = row_ < rows ? row_ : rows - 1;                                                         \
+        double val_ = 0.0;                                                                                        \
+        if ((S_).wlive) val_ = W[rowc_ * ldw + (S_).wcol];                                                        \
+        if ((S_).tlive) val_ = tau[rowc_];                                                                        \
+        (S_).t[i >> 2][i & 3] = row_ < rows ? val_ : 0.0;                                                         \
     }
-#define FIGH_WY_WAVE_SYNC()                                  \
-    do {                                                     \
+#define FIGH_WY_WAVE_SYNC()                                    \
+    do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_wave_barrier();                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+    // The front chunk retires: rotate the queue (register moves) and refill the freed slot at the back with the same
+    // chunk of the coming tile (full tiles only; `rn_` is its first row, opaque to the compiler so that the row
+    // addresses are not hoisted out of the loops).
+#define FIGH_WY_RETIRE(rn_)                                                            \
+    do {                                                                               \
+        Slot old_ = F;                                                                 \
+        F = Q[0];                                                                      \
+        _Pragma("unroll") for (int j = 0; j + 1 < NQ; ++j) Q[j] = Q[j + 1];            \
+        Q[NQ - 1].boff = old_.boff;                                                    \
+        Q[NQ - 1].wcol = old_.wcol;                                                    \
+        Q[NQ - 1].wlive = old_.wlive;                                                  \
+        Q[NQ - 1].tlive = old_.tlive;                                                  \
+        _Pragma("unroll") for (int rc = 0; rc < NRC; ++rc) Q[NQ - 1].t[rc] = old_.t[rc]; \
+        if (next_full) FIGH_WY_LOAD(Q[NQ - 1], rn_);                                   \
+        front += NW;                                                                   \
     } while (0)
 
     const long ntiles = (rows + M - 1) / M;
     int parity = 0;
+    int front = wave;       // chunk held by F; Q[j] holds front + NW (j + 1)
+    bool prefetched = false;  // the queue already holds the coming tile (every chunk retires once per tile)
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x, parity ^= 1) {
         const long r0 = t * M;
         const long r0n = (t + gridDim.x) * M;
         const bool next_full = r0n + M <= rows;  // only full tiles are prefetched
-        if (r0 + M <= rows) {
+        if (!prefetched) {
+            if (r0 + M <= rows) {
+                FIGH_WY_LOAD(F, r0);
 #pragma unroll
-            for (int s = 0; s < CPW; ++s)
-                if (!pf[s]) FIGH_WY_LOAD(s, r0);
-        } else {  // the last, ragged tile: rows clamped, then masked
+                for (int j = 0; j < NQ; ++j) FIGH_WY_LOAD(Q[j], r0);
+            } else {
+                FIGH_WY_LOAD_RAGGED(F, r0)
 #pragma unroll
-            for (int s = 0; s < CPW; ++s)
-#pragma unroll
-                for (int i = 0; i < RPL; ++i) {
-                    const long row = r0 + 16 * (i >> 2) + 4 * (i & 3) + g;
-                    const long rowc = row < rows ? row : rows - 1;
-                    double val = 0.0;
-                    if (wlive[s]) val = W[rowc * ldw + wcol[s]];
-                    if (tlive[s]) val = tau[rowc];
-                    T[s][i >> 2][i & 3] = row < rows ? val : 0.0;
-                }
+                for (int j = 0; j < NQ; ++j) { FIGH_WY_LOAD_RAGGED(Q[j], r0) }
+            }
         }
+        prefetched = next_full;
         if (blkw) {  // row-block weights (WLS): row r is scaled by blkw[r / rows_per_blk]
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const long row = r0 + 16 * (i >> 2) + 4 * (i & 3) + g;
                 const double scale = blkw[(row < rows ? row : rows - 1) / rows_per_blk];
+                F.t[i >> 2][i & 3] *= scale;
 #pragma unroll
-                for (int s = 0; s < CPW; ++s) T[s][i >> 2][i & 3] *= scale;
+                for (int j = 0; j < NQ; ++j) Q[j].t[i >> 2][i & 3] *= scale;
             }
         }
         // the first column with a non-zero in this tile: the column steps in front of it are identities (stacked
@@ -370,148 +400,127 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         for (int s = CPW - 1; s >= 0; --s) {
             bool nz = false;
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) nz |= (T[s][i >> 2][i & 3] != 0.0);
+            for (int i = 0; i < RPL; ++i) nz |= ((s == 0 ? F.t[i >> 2][i & 3] : Q[s > 0 ? s - 1 : 0].t[i >> 2][i & 3]) != 0.0);
             const unsigned long long b = __ballot(nz);
             const unsigned m16 = (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);
             if (m16) myfirst = 16 * (wave + NW * s) + __ffs((int)m16) - 1;
-            pf[s] = false;
         }
-        int p0;
-        if constexpr (NW > 1) {
-            if (lane == 0) fnz[parity][wave] = myfirst;
-            __syncthreads();
-            int first_nz = fnz[parity][0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) first_nz = min(first_nz, fnz[parity][w]);
-            p0 = __builtin_amdgcn_readfirstlane(first_nz) >> 4;
-        } else {
-            p0 = __builtin_amdgcn_readfirstlane(myfirst) >> 4;
-        }
-        FIGH_PROF_ADD(1);
-        if (p0 >= nch) continue;  // the tile is zero
-
-        // ---- the first panel of the tile has nobody to overlap with.  The slot-specific part (a real switch over the
-        // wave-uniform slot index) only stages the chunk in the LDS buffer that will receive V and refills the retired
-        // registers with the coming tile's chunk; the panel code itself is common and takes X from LDS, so no register
-        // value flows from a run-time-selected slot into it (that kind of merge made the allocator keep two copies of every
-        // slot: hundreds of spills at CPW >= 6).
-        if (wave == (p0 & (NW - 1))) {
-            __builtin_amdgcn_s_setprio(3);
-            const int so = p0 / NW;
-            double *Vn = vt[p0 & 1];
-            long rn = r0n;
-            asm volatile("" : "+s"(rn));  // opaque: the row addresses of the refill must not be hoisted out of the loops
-#define FIGH_WY_BODY(S_)                                                                               \
-    _Pragma("unroll") for (int i = 0; i < RPL; ++i)                                                    \
-        Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c] = T[S_][i >> 2][i & 3];                        \
-    if (next_full) {                                                                                   \
-        FIGH_WY_LOAD(S_, rn);                                                                          \
-        pf[S_] = true;                                                                                 \
-    }
-            FIGH_WY_SLOT_SWITCH(so, FIGH_WY_BODY)
-#undef FIGH_WY_BODY
-            double *bpp = block(p0, p0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = bpp[lane + 64 * r];
-            FIGH_WY_WAVE_SYNC();
-            double X[RPL];
-#pragma unroll
-            for (int i = 0; i < RPL; ++i) X[i] = Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c];
-            wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
-            FIGH_WY_WAVE_SYNC();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
-            __builtin_amdgcn_s_setprio(0);
-        }
+        if (lane == 0) fnz[parity][wave] = myfirst;
         __syncthreads();
-        FIGH_PROF_ADD(2);
+        int first_nz = fnz[parity][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) first_nz = min(first_nz, fnz[parity][w]);
+        int p0 = __builtin_amdgcn_readfirstlane(first_nz) >> 4;
+        if (p0 > nch) p0 = nch;
+        FIGH_PROF_ADD(1);
+        long rn = r0n;
+        asm volatile("" : "+s"(rn));
+        // chunks in front of the first non-zero column take no part in this tile
+        while (front < p0 && front < wave + NW * CPW) FIGH_WY_RETIRE(rn);
 
-        // ---- phase p: apply panel p to the trailing chunks; the owner of chunk p + 1 factors panel p + 1 meanwhile.
-        // The two blocks of the triangle that the owner's critical path starts with -- (p, p+1) for the chunk update,
-        // (p+1, p+1) for the panel -- were requested one phase earlier (rp_next, rq_next).
-        f64x4 rp_next = {0.0, 0.0, 0.0, 0.0}, rq_next = {0.0, 0.0, 0.0, 0.0};
-        bool have_next = false;
-        for (int p = p0; p + 1 < nch; ++p) {
-            const double *Vl = vt[p & 1];
-            const double *Tl = Vl + M * kLdv;
-            const int pn = p + 1;
-            const bool own_pn = wave == (pn & (NW - 1));
-            f64x4 rp = rp_next, rq = rq_next;
-            const bool have = have_next;
-            have_next = false;
-            if (pn + 1 < nch && wave == ((pn + 1) & (NW - 1))) {  // owner of the phase after this one
-                const double *b1 = block(pn, pn + 1), *b2 = block(pn + 1, pn + 1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    rp_next[r] = b1[lane + 64 * r];
-                    rq_next[r] = b2[lane + 64 * r];
-                }
-                have_next = true;
-            }
-            if (own_pn) {
-                // this wave is the critical path of the workgroup until panel p + 1 is published: it wins the issue
-                // arbitration against the waves it shares the SIMD with
+        if (p0 < nch) {
+            // ---- the first panel of the tile has nobody to overlap with
+            if (wave == (p0 & (NW - 1))) {
                 __builtin_amdgcn_s_setprio(3);
-                const int sn = pn / NW;
-                double *bpp = block(pn, pn);
-                if (!have) {
-                    const double *b1 = block(p, pn);
+                double *Vn = vt[p0 & 1];
+                double *bpp = block(p0, p0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        rp[r] = b1[lane + 64 * r];
-                        rq[r] = bpp[lane + 64 * r];
-                    }
-                }
-                double *bpn = block(p, pn);
-                double *Vn = vt[pn & 1];
-                long rn = r0n;
-                asm volatile("" : "+s"(rn));
-#define FIGH_WY_BODY(S_)                                                                               \
-    wy_update_chunk<NRC>(T[S_], Vl, Tl, rp, bpn, lane, c, g);                                           \
-    FIGH_PROF_ADD(7);                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < RPL; ++i)                                                    \
-        Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c] = T[S_][i >> 2][i & 3];                        \
-    if (next_full) {                                                                                   \
-        FIGH_WY_LOAD(S_, rn);                                                                          \
-        pf[S_] = true;                                                                                 \
-    }
-                FIGH_WY_SLOT_SWITCH(sn, FIGH_WY_BODY)
-#undef FIGH_WY_BODY
-                FIGH_PROF_ADD(3);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = rq[r];
-                FIGH_WY_WAVE_SYNC();
+                for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = bpp[lane + 64 * r];
                 double X[RPL];
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) X[i] = Vn[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c];
+                for (int i = 0; i < RPL; ++i) X[i] = F.t[i >> 2][i & 3];
                 wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
                 FIGH_WY_WAVE_SYNC();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
+                FIGH_WY_RETIRE(rn);
                 __builtin_amdgcn_s_setprio(0);
-                FIGH_PROF_ADD(4);
             }
+            __syncthreads();
+            FIGH_PROF_ADD(2);
+
+            // ---- phase p: apply panel p to the trailing chunks; the owner of chunk p + 1 updates that chunk first and
+            // factors panel p + 1 meanwhile.  The block (p, p+1) of the triangle that the owner starts with was requested
+            // one phase earlier (rp_next); the diagonal block (p+1, p+1) is requested at the start of the phase and has
+            // the chunk update to arrive.
+            f64x4 rp_next = {0.0, 0.0, 0.0, 0.0};
+            bool have_next = false;
+            for (int p = p0; p + 1 < nch; ++p) {
+                const double *Vl = vt[p & 1];
+                const double *Tl = Vl + M * kLdv;
+                const int pn = p + 1;
+                f64x4 rp = rp_next;
+                const bool have = have_next;
+                have_next = false;
+                if (pn + 1 < nch && wave == ((pn + 1) & (NW - 1))) {  // owner of the phase after this one
+                    const double *b1 = block(pn, pn + 1);
 #pragma unroll
-            for (int s = 0; s < CPW; ++s) {
-                const int cc = wave + NW * s;
-                if (cc > pn && cc < nch) {
-                    double *b = block(p, cc);
+                    for (int r = 0; r < 4; ++r) rp_next[r] = b1[lane + 64 * r];
+                    have_next = true;
+                }
+                if (wave == (pn & (NW - 1))) {  // front == pn
+                    // this wave is the critical path of the workgroup until panel p + 1 is published: it wins the
+                    // issue arbitration against the waves it shares the SIMD with
+                    __builtin_amdgcn_s_setprio(3);
+                    double *bpp = block(pn, pn);
+                    f64x4 rq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rq[r] = bpp[lane + 64 * r];
+                    if (!have) {
+                        const double *b1 = block(p, pn);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rp[r] = b1[lane + 64 * r];
+                    }
+                    wy_update_chunk<NRC>(F.t, Vl, Tl, rp, block(p, pn), lane, c, g);
+                    FIGH_PROF_ADD(3);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = rq[r];
+                    double *Vn = vt[pn & 1];
+                    double X[RPL];
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) X[i] = F.t[i >> 2][i & 3];
+                    wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
+                    FIGH_WY_WAVE_SYNC();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
+                    FIGH_WY_RETIRE(rn);
+                    __builtin_amdgcn_s_setprio(0);
+                    FIGH_PROF_ADD(4);
+                }
+                // every chunk behind panel p + 1 (the owner's queue has already moved on: its F is its next chunk)
+                if (front > pn && front < nch) {
+                    double *b = block(p, front);
                     f64x4 rb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) rb[r] = b[lane + 64 * r];
-                    wy_update_chunk<NRC>(T[s], Vl, Tl, rb, b, lane, c, g);
+                    wy_update_chunk<NRC>(F.t, Vl, Tl, rb, b, lane, c, g);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: hoisting the next chunk's operands costs registers
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const int cc = front + NW * (j + 1);
+                    if (cc > pn && cc < nch) {
+                        double *b = block(p, cc);
+                        f64x4 rb;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rb[r] = b[lane + 64 * r];
+                        wy_update_chunk<NRC>(Q[j].t, Vl, Tl, rb, b, lane, c, g);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                FIGH_PROF_ADD(5);
+                __syncthreads();
+                FIGH_PROF_ADD(6);
             }
-            FIGH_PROF_ADD(5);
-            __syncthreads();
-            FIGH_PROF_ADD(6);
         }
+        // slots beyond the last chunk of the matrix (and, for a zero tile, everything) leave the queue unused
+        while (front < wave + NW * CPW) FIGH_WY_RETIRE(rn);
+        front = wave;
     }
 #undef FIGH_WY_LOAD
+#undef FIGH_WY_LOAD_RAGGED
 #undef FIGH_WY_WAVE_SYNC
-#undef FIGH_WY_SLOT_SWITCH
-#undef FIGH_WY_SLOT_CASE
+#undef FIGH_WY_RETIRE
     FIGH_PROF_STORE(prof, wave, NW);
 
     // ---- write this wave's columns of the nc x nc row-major triangle (zeros below the diagonal)
@@ -579,6 +588,8 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
     FIGH_WY_CASE(8, 3, 4, 2)
     FIGH_WY_CASE(8, 4, 4, 2)
 #ifdef FIGH_ABLATION
+    FIGH_WY_CASE(4, 6, 3, 2)
+    FIGH_WY_CASE(4, 4, 3, 2)
     FIGH_WY_CASE(8, 2, 4, 3)
     FIGH_WY_CASE(8, 2, 4, 2)
     FIGH_WY_CASE(4, 3, 4, 1)
@@ -639,9 +650,9 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
             for (int k = 0; k < 12; ++k) acc[k] += (double)h[12 * w + k];
         const long ntiles = (rows + 16 * pcfg.nrc - 1) / (16 * pcfg.nrc);
         fprintf(stderr, "[wy prof] cfg %d,%d,%d,%d nc %d wgs %ld (occupancy %ld/CU) tiles/wg %.1f | ticks per wave: kernel %.0f = top %.0f + "
-                        "first panel %.0f + la-update %.0f + la-stage %.0f + la-panel %.0f + updates %.0f + barrier %.0f\n",
+                        "first panel %.0f + la-update %.0f + (unused %.0f) + la-panel %.0f + updates %.0f + barrier %.0f\n",
                 pcfg.nw, pcfg.cpw, pcfg.nrc, pcfg.wpe, nc, nwg, tsqr_wide_workgroups(nc, 1), (double)ntiles / nwg, acc[0] / nwv, acc[1] / nwv,
-                acc[2] / nwv, acc[7] / nwv, acc[3] / nwv, acc[4] / nwv, acc[5] / nwv, acc[6] / nwv);
+                acc[2] / nwv, acc[3] / nwv, acc[7] / nwv, acc[4] / nwv, acc[5] / nwv, acc[6] / nwv);
     }
 #endif
     return FIGH_OK;
