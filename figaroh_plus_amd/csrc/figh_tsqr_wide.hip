@@ -429,12 +429,16 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                 double X[RPL];
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) X[i] = F.t[i >> 2][i & 3];
+                FIGH_WY_WAVE_SYNC();
+                FIGH_PROF_ADD(8);
                 wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
                 FIGH_WY_WAVE_SYNC();
+                FIGH_PROF_ADD(9);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
                 FIGH_WY_RETIRE(rn);
                 __builtin_amdgcn_s_setprio(0);
+                FIGH_PROF_ADD(10);
             }
             __syncthreads();
             FIGH_PROF_ADD(2);
@@ -479,13 +483,16 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     double X[RPL];
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) X[i] = F.t[i >> 2][i & 3];
+                    FIGH_WY_WAVE_SYNC();
+                    FIGH_PROF_ADD(7);
                     wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
                     FIGH_WY_WAVE_SYNC();
+                    FIGH_PROF_ADD(4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
                     FIGH_WY_RETIRE(rn);
                     __builtin_amdgcn_s_setprio(0);
-                    FIGH_PROF_ADD(4);
+                    FIGH_PROF_ADD(11);
                 }
                 // every chunk behind panel p + 1 (the owner's queue has already moved on: its F is its next chunk)
                 if (front > pn && front < nch) {
@@ -571,7 +578,7 @@ WyConfig wy_config(const int nc) {
 #endif
     if (nch <= 12) return {4, 3, 4, 2};
     if (nch <= 16) return {4, 4, 4, 2};
-    if (nch <= 24) return {8, 3, 4, 2};
+    if (nch <= 24) return {4, 6, 3, 2};
     return {8, 4, 4, 2};
 }
 
@@ -585,10 +592,10 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
     }
     FIGH_WY_CASE(4, 3, 4, 2)
     FIGH_WY_CASE(4, 4, 4, 2)
-    FIGH_WY_CASE(8, 3, 4, 2)
+    FIGH_WY_CASE(4, 6, 3, 2)
     FIGH_WY_CASE(8, 4, 4, 2)
 #ifdef FIGH_ABLATION
-    FIGH_WY_CASE(4, 6, 3, 2)
+    FIGH_WY_CASE(8, 3, 4, 2)
     FIGH_WY_CASE(4, 4, 3, 2)
     FIGH_WY_CASE(8, 2, 4, 3)
     FIGH_WY_CASE(8, 2, 4, 2)
@@ -650,9 +657,9 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
             for (int k = 0; k < 12; ++k) acc[k] += (double)h[12 * w + k];
         const long ntiles = (rows + 16 * pcfg.nrc - 1) / (16 * pcfg.nrc);
         fprintf(stderr, "[wy prof] cfg %d,%d,%d,%d nc %d wgs %ld (occupancy %ld/CU) tiles/wg %.1f | ticks per wave: kernel %.0f = top %.0f + "
-                        "first panel %.0f + la-update %.0f + (unused %.0f) + la-panel %.0f + updates %.0f + barrier %.0f\n",
+                        "first panel wait %.0f [owner: load %.0f panel %.0f retire %.0f] + la-update %.0f + la-X %.0f + la-panel %.0f + la-retire %.0f + updates %.0f + barrier %.0f\n",
                 pcfg.nw, pcfg.cpw, pcfg.nrc, pcfg.wpe, nc, nwg, tsqr_wide_workgroups(nc, 1), (double)ntiles / nwg, acc[0] / nwv, acc[1] / nwv,
-                acc[2] / nwv, acc[3] / nwv, acc[7] / nwv, acc[4] / nwv, acc[5] / nwv, acc[6] / nwv);
+                acc[2] / nwv, acc[8] / nwv, acc[9] / nwv, acc[10] / nwv, acc[3] / nwv, acc[7] / nwv, acc[4] / nwv, acc[11] / nwv, acc[5] / nwv, acc[6] / nwv);
     }
 #endif
     return FIGH_OK;
