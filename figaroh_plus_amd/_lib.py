@@ -69,6 +69,7 @@ SIGNATURES = {
     "figh_filtfilt_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _c_double_p, _c_double_p,
                                      C.c_int, C.c_int, _c_double_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int64)]),
+    "figh_comm_available": (C.c_int, []),
     "figh_comm_unique_id": (C.c_int, [C.c_void_p]),
     "figh_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "figh_comm_destroy": (C.c_int, []),

@@ -216,8 +216,8 @@ int figh_synchronize(void) {
     return FIGH_OK;
 }
 
-int figh_profile_enable(int on) {
-    g_profile = on < 0 ? 0 : (on > 2 ? 2 : on);
+int figh_profile_enable(int level) {
+    g_profile = level < 0 ? 0 : (level > 2 ? 2 : level);
     return FIGH_OK;
 }
 

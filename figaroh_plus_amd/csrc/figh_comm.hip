@@ -68,6 +68,11 @@ using namespace figh;
 
 extern "C" {
 
+int figh_comm_available(void) {
+    if (int rc = ensure_device()) return rc;
+    return load_rccl();
+}
+
 int figh_comm_unique_id(void *h_id128) {
     FIGH_REQUIRE(h_id128, "h_id128 is NULL");
     if (int rc = load_rccl()) return rc;

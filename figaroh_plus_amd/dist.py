@@ -72,21 +72,18 @@ class TorchExchange:
 class RcclExchange:
     """Exchange on device buffers with RCCL over xGMI (``figh_comm_*``)."""
 
-    def __init__(self, world_size, rank, broadcast_bytes):
-        """``broadcast_bytes(payload_or_None) -> bytes``: ships rank 0's 128-byte id to every rank."""
+    def __init__(self, world_size, rank, ident):
+        """``ident``: rank 0's 128-byte ncclUniqueId (see :func:`rccl_unique_id`), already shipped to this rank.
+        Callers must have agreed beforehand that EVERY rank can build the communicator (:func:`rccl_preflight`):
+        ncclCommInitRank blocks until all ranks have joined."""
         import ctypes as C
 
         from . import _lib
 
         self._lib = _lib
         self.world_size, self.rank = world_size, rank
-        lib = _lib.load()
-        buf = C.create_string_buffer(128)
-        if rank == 0:
-            _lib.check(lib.figh_comm_unique_id(buf))
-        payload = broadcast_bytes(bytes(buf.raw) if rank == 0 else None)
-        ident = C.create_string_buffer(payload, 128)
-        _lib.check(lib.figh_comm_init(world_size, rank, ident))
+        buf = C.create_string_buffer(bytes(ident), 128)
+        _lib.check(_lib.load().figh_comm_init(world_size, rank, buf))
 
     def sum_columns(self, d_colsq, ncols):
         self._lib.check(self._lib.load().figh_comm_allreduce_sum(d_colsq.ptr, ncols))
@@ -104,41 +101,77 @@ class RcclExchange:
         self._lib.load().figh_comm_destroy()
 
 
-def exchange_from_env(prefer="rccl"):
+def rccl_preflight():
+    """Local check, no communication: (ok, reason).  librccl loads with every symbol and a HIP device is present."""
+    from . import _lib
+
+    try:
+        _lib.check(_lib.load().figh_comm_available())
+        return True, ""
+    except Exception as e:  # noqa: BLE001
+        return False, str(e)
+
+
+def rccl_unique_id():
+    """Rank 0: a fresh 128-byte ncclUniqueId."""
+    import ctypes as C
+
+    from . import _lib
+
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().figh_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+
+def exchange_from_env(prefer="rccl", device_key=None):
     """Build the exchange for a ``torch.distributed.run`` launch (RANK / WORLD_SIZE / MASTER_* in the env).
 
     Returns (exchange, info).  World size 1 -> the single-process no-op exchange.
+
+    The RCCL set-up runs in phases so that no failure can leave a rank blocked in a collective:
+
+    1. every rank runs the local preflight and states which device it drives (``device_key``, default
+       ``(hostname, LOCAL_RANK)``); the outcomes are all-gathered over the gloo control plane;
+    2. only if EVERY rank passed and no two ranks share a device (RCCL needs one GPU per rank) does rank 0 create the
+       unique id; the id broadcast is executed by every rank in either case (an empty payload = "no RCCL");
+    3. all ranks call ``ncclCommInitRank``.  A failure from here on is not recoverable collectively: the exception
+       propagates, the process exits non-zero and the launcher tears the job down.
+
+    Otherwise all ranks take the host-staged exchange -- decided collectively, reported in the bench line.
     """
     from .pipeline import Exchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
         return Exchange(), {"collective": "none"}
+    import socket
+
     import torch.distributed as dist
 
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")  # control plane only: id exchange + barriers
     rank = dist.get_rank()
-    if prefer == "rccl":
-        def bcast(payload):
-            obj = [payload]
-            dist.broadcast_object_list(obj, src=0)
-            return obj[0]
-
-        # RCCL needs one distinct GPU per rank; if the communicator cannot be built on ANY rank (e.g. two ranks
-        # sharing a device in a test), every rank takes the host-staged exchange instead -- decided collectively
-        # so that no rank is left waiting in a collective, and reported in the bench line.
-        ex, err = None, ""
+    if prefer != "rccl":
+        return TorchExchange(), {"collective": "torch.distributed/" + dist.get_backend()}
+    # phase 1
+    ok, why = rccl_preflight()
+    if device_key is None:
+        device_key = (socket.gethostname(), int(os.environ.get("LOCAL_RANK", rank)))
+    states = [None] * world
+    dist.all_gather_object(states, (bool(ok), why, tuple(device_key)))
+    all_ok = all(s[0] for s in states)
+    distinct = len({s[2] for s in states}) == world
+    # phase 2 (every rank takes part in the broadcast, whatever phase 1 said)
+    payload = [None]
+    if rank == 0 and all_ok and distinct:
         try:
-            ex = RcclExchange(world, rank, bcast)
+            payload[0] = rccl_unique_id()
         except Exception as e:  # noqa: BLE001
-            err = str(e)
-        flags = [None] * world
-        dist.all_gather_object(flags, ex is not None)
-        if all(flags):
-            return ex, {"collective": "rccl"}
-        if ex is not None:
-            ex.close()
-        return TorchExchange(), {"collective": "torch.distributed/gloo host-staged (rccl unavailable: %s)" % err[:80]}
-    return TorchExchange(), {"collective": "torch.distributed/" + dist.get_backend()}
+            why = str(e)
+    dist.broadcast_object_list(payload, src=0)
+    if payload[0] is None:
+        reason = "two ranks share a device" if (all_ok and not distinct) else next((s[1] for s in states if not s[0]), why)
+        return TorchExchange(), {"collective": "torch.distributed/gloo host-staged (rccl unavailable: %s)" % reason[:80]}
+    # phase 3
+    return RcclExchange(world, rank, payload[0]), {"collective": "rccl"}

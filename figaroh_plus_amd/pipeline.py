@@ -65,14 +65,21 @@ class IdentificationPipeline:
 
     # ------------------------------------------------------------------ inputs
     def set_samples(self, q, v, a, tau=None):
-        """Upload this rank's samples (q: N x nq, v/a: N x nv) and optionally tau (rows of W,)."""
-        q = np.ascontiguousarray(q, dtype=np.float64)
-        self.N = len(q)
-        self.d_q = _lib.DeviceArray.from_host(q.reshape(-1))
-        self.d_v = _lib.DeviceArray.from_host(np.ascontiguousarray(v, dtype=np.float64).reshape(-1))
-        self.d_a = _lib.DeviceArray.from_host(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
-        self.d_tau = None if tau is None else _lib.DeviceArray.from_host(
-            np.ascontiguousarray(tau, dtype=np.float64).reshape(-1))
+        """Upload this rank's samples (q: N x nq, v/a: N x nv) and optionally tau (rows of W,).
+
+        Shapes are checked here, before anything reaches the device: the kernels index q, v, a and tau with N and the
+        model's nq / nv, so a mismatched array would be read past its HBM allocation."""
+        from .tools.regressor import _samples_to_device, regressor_flags
+        mode, _, _ = regressor_flags(self.param, self.coupling)
+        rps = self.robot.model.nv if mode == _lib.MODE_JOINT_TORQUE else 6  # figh_regressor_shape
+        if tau is not None:
+            tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(-1)
+            if tau.shape[0] != rps * len(q):
+                raise ValueError("tau must have rows_per_sample * N = %d * %d = %d entries; got %d"
+                                 % (rps, len(q), rps * len(q), tau.shape[0]))
+        N, d_q, d_v, d_a = _samples_to_device(self.robot.model, q, v, a)  # raises ValueError on a shape mismatch
+        d_tau = None if tau is None else _lib.DeviceArray.from_host(tau)
+        self.N, self.d_q, self.d_v, self.d_a, self.d_tau = N, d_q, d_v, d_a, d_tau
         self.W = None
 
     def _chunks(self):

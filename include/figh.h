@@ -64,7 +64,7 @@ int figh_synchronize(void);
  * "tsqr": a few event records per pass, cheap enough to stay on inside a timed region); 2 times every launch.
  * figh_profile_get: name is the kernel family ("regressor_chain", "regressor_tree", "tsqr", "colsq", ...);
  * returns launches and total milliseconds since the last figh_profile_reset(). */
-int figh_profile_enable(int on);
+int figh_profile_enable(int level);
 int figh_profile_reset(void);
 int figh_profile_get(const char *name, int *launches, double *total_ms);
 
@@ -175,7 +175,11 @@ int figh_filtfilt_cols(const double *d_X, int64_t rows, int cols, int64_t ldx, i
 
 /* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI), SURVEY.md section 8e
  * One process per GPU.  Rank 0 calls figh_comm_unique_id and ships the 128 bytes to the other ranks by any
- * means (the Python side uses the torch.distributed store); every rank then calls figh_comm_init. */
+ * means (the Python side uses the torch.distributed store); every rank then calls figh_comm_init.
+ * figh_comm_available is the local preflight (librccl loads, every symbol resolves, a HIP device is there): the ranks
+ * agree on its outcome BEFORE anybody enters ncclCommInitRank, so that a rank without RCCL cannot leave the others
+ * blocked in the rendezvous. */
+int figh_comm_available(void);
 int figh_comm_unique_id(void *h_id128);
 int figh_comm_init(int nranks, int rank, const void *h_id128);
 int figh_comm_destroy(void);

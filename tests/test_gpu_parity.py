@@ -318,6 +318,7 @@ def test_rccl_single_rank_roundtrip(lib):
     import ctypes as C
     buf = C.create_string_buffer(128)
     l = lib.load()
+    lib.check(l.figh_comm_available())  # the local preflight of dist.exchange_from_env
     lib.check(l.figh_comm_unique_id(buf))
     lib.check(l.figh_comm_init(1, 0, buf))
     try:

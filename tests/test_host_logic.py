@@ -110,3 +110,19 @@ def test_regressor_flags_and_errors(golden):
     neither = dict(golden.param, is_joint_torques=False, is_external_wrench=False)
     with pytest.raises(UnboundLocalError):
         regressor_flags(neither)
+
+
+def test_pipeline_rejects_mismatched_sample_shapes(golden_ur10):
+    """IdentificationPipeline.set_samples must validate shapes before anything is uploaded (a wrong v / a /
+    tau would be read past its HBM allocation by K1 / K3).  No device is needed: the checks run first."""
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    g = golden_ur10
+    pipe = IdentificationPipeline(g.robot(), g.param, params_std=g.params_std())
+    q, v, a = g["q_big"], g["v_big"], g["a_big"]
+    N = len(q)
+    with pytest.raises(ValueError):
+        pipe.set_samples(q, v[:, :5], a)                 # v with nv - 1 columns
+    with pytest.raises(ValueError):
+        pipe.set_samples(q, v, a[:N - 1])                # a with a row missing
+    with pytest.raises(ValueError):
+        pipe.set_samples(q, v, a, tau=np.zeros(6 * N + 1))  # tau from another run
