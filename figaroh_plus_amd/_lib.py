@@ -47,6 +47,8 @@ SIGNATURES = {
     "figh_regressor_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "figh_regressor_build": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "figh_regressor_build_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "figh_coupling_tx40": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "figh_colsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p]),
     "figh_gather_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -214,6 +216,12 @@ class ModelHandle:
             idx_q.ctypes.data_as(_c_int32_p), idx_v.ctypes.data_as(_c_int32_p),
             gravity.ctypes.data_as(_c_double_p), body_mask.ctypes.data_as(_c_int32_p), C.byref(h)))
         self.handle = h.value
+        # the library's own criterion (figh_model_create): fixed-base serial chain of <= 8 revolute joints
+        self._chain = n - 1 <= 8 and all(int(jtype[i]) == 0 and int(parents[i]) == i - 1 for i in range(1, n))
+
+    def is_chain(self):
+        """True when the joint-torque regressor of this model is built by the chain kernel (dense row tiles)."""
+        return self._chain
 
     def shape(self, mode, flags):
         r, c = C.c_int(0), C.c_int(0)
@@ -236,6 +244,13 @@ class ModelHandle:
 def regressor_build(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_W, ldw, d_colsq=None):
     check(load().figh_regressor_build(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr, d_W.ptr, ldw,
                                       d_colsq.ptr if d_colsq is not None else None))
+
+
+def regressor_build_padded(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_W, ldw, d_colsq=None):
+    """Link-padded W (16 columns per link) for device-resident use; ``d_W`` may be None (column norms only)."""
+    check(load().figh_regressor_build_padded(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr,
+                                             d_W.ptr if d_W is not None else None, ldw,
+                                             d_colsq.ptr if d_colsq is not None else None))
 
 
 def coupling_tx40(N, nv, d_v, d_a, d_out):

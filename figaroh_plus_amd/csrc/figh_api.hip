@@ -309,6 +309,7 @@ int figh_model_create(int njoints, const int32_t *parents, const int32_t *jtype,
 int figh_model_destroy(figh_model_t model) {
     if (!model) return FIGH_OK;
     if (g_ready) (void)hipStreamSynchronize(g_stream);
+    forget_tapes(model);
     if (model->dev) (void)hipFree(model->dev);
     delete model;
     return FIGH_OK;

@@ -66,6 +66,12 @@ extern "C" void figh_tsqr_hint_end(void);
 
 namespace figh {
 
+// figh_regressor_tree.hip: K1' for kinematic trees (tape-driven); *colsq_done = 1 when diag(W^T W) was fused
+int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mask, long N, const double *q,
+                          const double *v, const double *a, double *W, long ldw, int ncols, int link_stride,
+                          double *d_colsq, int *colsq_done);
+void forget_tapes(const figh_model_s *m);
+
 // figh_tsqr_wide.hip: the blocked (compact-WY, MFMA) level for nc > 80 columns
 long tsqr_wide_workgroups(int nc, int cus);
 int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,

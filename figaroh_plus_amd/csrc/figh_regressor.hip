@@ -5,7 +5,7 @@
 // add_coupling_TX40 (:198-227).  Output is written directly in the reference's layout: row r = j*N + i
 // (joint-major), 14 columns per link in FIGAROH order.
 //
-// Two kernels:
+// Two kernels (the second one in figh_regressor_tree.hip):
 //
 //  regressor_chain_kernel<NJ>   fixed-base serial chains of revolute joints (TX40, UR10: BASELINE configs 1-2).
 //      One wavefront = a tile of 64 consecutive samples, one sample per lane.  The tree constants arrive as a
@@ -18,52 +18,16 @@
 //      coalesced run of 16-byte stores (43 KB for UR10).  HBM-write bound: 8*(3*NJ) B read + 8*NJ*ncols B
 //      written per sample.
 //
-//  regressor_tree_kernel<MAXJ>  any tree (TIAGo, TALOS, human: free-flyer, prismatic, continuous joints,
-//      external-wrench mode).  One sample per lane, Pinocchio's forward/backward recursion with the per-joint
-//      placements and velocities in per-lane scratch arrays; entries are scattered into a zero-filled W.
+//  regressor_tape_kernel (figh_regressor_tree.hip)  any tree (TIAGo, TALOS, human: free-flyer, prismatic, continuous
+//      joints, external-wrench mode).
 //
 // All arithmetic is fp64.  6-vectors are (linear, angular).
 #include <cmath>
 
 #include "figh_internal.h"
+#include "figh_spatial.h"
 
 namespace figh {
-
-__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
-    c[0] = a[1] * b[2] - a[2] * b[1];
-    c[1] = a[2] * b[0] - a[0] * b[2];
-    c[2] = a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ void rot(const double *R, const double *x, double *y) {  // y = R x
-    y[0] = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
-    y[1] = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
-    y[2] = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
-}
-__device__ __forceinline__ void rotT(const double *R, const double *x, double *y) {  // y = R^T x
-    y[0] = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
-    y[1] = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
-    y[2] = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
-}
-__device__ __forceinline__ void rodrigues(const double *a, double c, double s, double *R) {
-    const double t = 1.0 - c;
-    R[0] = 1.0 - t * (a[2] * a[2] + a[1] * a[1]);
-    R[1] = t * a[0] * a[1] - s * a[2];
-    R[2] = t * a[0] * a[2] + s * a[1];
-    R[3] = t * a[0] * a[1] + s * a[2];
-    R[4] = 1.0 - t * (a[2] * a[2] + a[0] * a[0]);
-    R[5] = t * a[1] * a[2] - s * a[0];
-    R[6] = t * a[0] * a[2] - s * a[1];
-    R[7] = t * a[1] * a[2] + s * a[0];
-    R[8] = 1.0 - t * (a[1] * a[1] + a[0] * a[0]);
-}
-__device__ __forceinline__ void matmul3(const double *A, const double *B, double *C) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
-}
-__device__ __forceinline__ double sgn(double x) { return (double)((x > 0.0) - (x < 0.0)); }
 
 // ---------------------------------------------------------------------------------------------- chain kernel
 template <int NJ>
@@ -338,228 +302,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (threadIdx.x == 0) out[c] = sm[0];
 }
 
-// ---------------------------------------------------------------------------------------------- tree kernel
-__constant__ int kPinToFig[10] = {9, 6, 7, 8, 0, 1, 3, 2, 4, 5};
-
-template <int MAXJ>
-__global__ __launch_bounds__(256) void regressor_tree_kernel(const DevModel *__restrict__ M, const int mode,
-                                                             const int flags, const int ft_mask, const long N,
-                                                             const double *__restrict__ q,
-                                                             const double *__restrict__ v,
-                                                             const double *__restrict__ a, double *__restrict__ W,
-                                                             const long ldw) {
-    const int n = M->njoints, nq = M->nq, nv = M->nv, nl = n - 1;
-    const bool fric = flags & FIGH_FLAG_FRICTION, actin = flags & FIGH_FLAG_ACT_INERTIA, offs = flags & FIGH_FLAG_OFFSET;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const double *qi = q + i * nq, *vi = v + i * nv, *ai = a + i * nv;
-        double liR[MAXJ][9], liP[MAXJ][3], V[MAXJ][6], A[MAXJ][6];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            V[0][d] = 0.0;
-            V[0][3 + d] = 0.0;
-            A[0][d] = -M->gravity[d];
-            A[0][3 + d] = 0.0;
-        }
-        // ---- forward pass (restates the first loop of pinocchio::computeJointTorqueRegressor)
-        for (int k = 1; k < n; ++k) {
-            const int jt = M->jtype[k], iq = M->idx_q[k], iv = M->idx_v[k], par = M->parents[k];
-            const double ax[3] = {M->axis[k][0], M->axis[k][1], M->axis[k][2]};
-            double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0}, vj[6] = {0, 0, 0, 0, 0, 0},
-                   aj[6] = {0, 0, 0, 0, 0, 0};
-            if (jt == FIGH_JT_REVOLUTE || jt == FIGH_JT_CONTINUOUS) {
-                double s, c;
-                if (jt == FIGH_JT_REVOLUTE) {
-                    sincos(qi[iq], &s, &c);
-                } else {
-                    c = qi[iq];
-                    s = qi[iq + 1];
-                }
-                rodrigues(ax, c, s, Rj);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    vj[3 + d] = ax[d] * vi[iv];
-                    aj[3 + d] = ax[d] * ai[iv];
-                }
-            } else if (jt == FIGH_JT_PRISMATIC) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    pj[d] = ax[d] * qi[iq];
-                    vj[d] = ax[d] * vi[iv];
-                    aj[d] = ax[d] * ai[iv];
-                }
-            } else {  // free-flyer: q = [p, qx qy qz qw], v in the joint's local frame
-                const double x = qi[iq + 3], y = qi[iq + 4], z = qi[iq + 5], ww = qi[iq + 6];
-                Rj[0] = 1 - 2 * (y * y + z * z); Rj[1] = 2 * (x * y - z * ww); Rj[2] = 2 * (x * z + y * ww);
-                Rj[3] = 2 * (x * y + z * ww); Rj[4] = 1 - 2 * (x * x + z * z); Rj[5] = 2 * (y * z - x * ww);
-                Rj[6] = 2 * (x * z - y * ww); Rj[7] = 2 * (y * z + x * ww); Rj[8] = 1 - 2 * (x * x + y * y);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) pj[d] = qi[iq + d];
-#pragma unroll
-                for (int d = 0; d < 6; ++d) {
-                    vj[d] = vi[iv + d];
-                    aj[d] = ai[iv + d];
-                }
-            }
-            double Rk[9], pk[3];
-            matmul3(M->placement[k], Rj, Rk);
-            rot(M->placement[k], pj, pk);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) pk[d] += M->placement[k][9 + d];
-            double Vp[6], Ap[6], t1[3], t2[3], Vk[6], Ak[6];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                Vp[d] = V[par][d];
-                Ap[d] = A[par][d];
-            }
-            cross3(pk, Vp + 3, t1);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t2[d] = Vp[d] - t1[d];
-            rotT(Rk, t2, Vk);
-            rotT(Rk, Vp + 3, Vk + 3);
-            cross3(pk, Ap + 3, t1);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t2[d] = Ap[d] - t1[d];
-            rotT(Rk, t2, Ak);
-            rotT(Rk, Ap + 3, Ak + 3);
-#pragma unroll
-            for (int d = 0; d < 6; ++d) Vk[d] += vj[d];
-            // Vk x vj
-            double c1[3], c2[3], c3[3];
-            cross3(Vk + 3, vj, c1);
-            cross3(Vk, vj + 3, c2);
-            cross3(Vk + 3, vj + 3, c3);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                Ak[d] += aj[d] + c1[d] + c2[d];
-                Ak[3 + d] += aj[3 + d] + c3[d];
-            }
-#pragma unroll
-            for (int d = 0; d < 9; ++d) liR[k][d] = Rk[d];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) liP[k][d] = pk[d];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                V[k][d] = Vk[d];
-                A[k][d] = Ak[d];
-            }
-        }
-        // ---- backward pass: body regressor of link b carried up its ancestor chain
-        for (int b = n - 1; b >= 1; --b) {
-            if (mode == FIGH_MODE_EXT_WRENCH && !M->body_mask[b]) continue;  // regressor.py:36-39,96-138
-            double B[10][6];
-            {
-                const double vl[3] = {V[b][0], V[b][1], V[b][2]}, om[3] = {V[b][3], V[b][4], V[b][5]};
-                const double al[3] = {A[b][0], A[b][1], A[b][2]}, da[3] = {A[b][3], A[b][4], A[b][5]};
-                double t[3], acc[3];
-                cross3(om, vl, t);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) acc[d] = al[d] + t[d];
-#pragma unroll
-                for (int c = 0; c < 10; ++c)
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) B[c][r] = 0.0;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) B[0][d] = acc[d];
-                // cols 1-3: lin = (skew(da) + skew(om)^2)[:, c], ang = -skew(acc)[:, c]
-                const double sw[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
-                const double sd[9] = {0, -da[2], da[1], da[2], 0, -da[0], -da[1], da[0], 0};
-                const double sa[9] = {0, -acc[2], acc[1], acc[2], 0, -acc[0], -acc[1], acc[0], 0};
-                double sw2[9];
-                matmul3(sw, sw, sw2);
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        B[1 + c][r] = sd[3 * r + c] + sw2[3 * r + c];
-                        B[1 + c][3 + r] = -sa[3 * r + c];
-                    }
-                // cols 4-9: ang = (L(da) + skew(om) L(om))[:, c]
-                const double Ld[18] = {da[0], da[1], 0, da[2], 0, 0, 0, da[0], da[1], 0, da[2], 0, 0, 0, 0, da[0], da[1], da[2]};
-                const double Lw[18] = {om[0], om[1], 0, om[2], 0, 0, 0, om[0], om[1], 0, om[2], 0, 0, 0, 0, om[0], om[1], om[2]};
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        B[4 + c][3 + r] = Ld[6 * r + c] + sw[3 * r] * Lw[c] + sw[3 * r + 1] * Lw[6 + c] + sw[3 * r + 2] * Lw[12 + c];
-            }
-            for (int j = b; j > 0; j = M->parents[j]) {
-                const int jt = M->jtype[j], iv = M->idx_v[j];
-                const bool emit = mode == FIGH_MODE_JOINT_TORQUE || iv < 6;
-                if (emit) {
-                    const double ax[3] = {M->axis[j][0], M->axis[j][1], M->axis[j][2]};
-                    const int ndof = jt == FIGH_JT_FREEFLYER ? 6 : 1;
-                    for (int r = 0; r < ndof; ++r) {
-                        const int dof = iv + r;
-                        if (mode == FIGH_MODE_EXT_WRENCH && (dof >= 6 || !((ft_mask >> dof) & 1))) continue;
-                        double *row = W + ((long)dof * N + i) * ldw + 14 * (b - 1);
-#pragma unroll
-                        for (int c = 0; c < 10; ++c) {
-                            double val;
-                            if (jt == FIGH_JT_FREEFLYER) {
-                                val = r == 0 ? B[c][0] : r == 1 ? B[c][1] : r == 2 ? B[c][2] : r == 3 ? B[c][3] : r == 4 ? B[c][4] : B[c][5];
-                            } else if (jt == FIGH_JT_PRISMATIC) {
-                                val = ax[0] * B[c][0] + ax[1] * B[c][1] + ax[2] * B[c][2];
-                            } else {
-                                val = ax[0] * B[c][3] + ax[1] * B[c][4] + ax[2] * B[c][5];
-                            }
-                            row[kPinToFig[c]] = val;
-                        }
-                    }
-                }
-                if (M->parents[j] == 0) break;  // nothing above to feed
-                double Rk[9], pk[3];
-#pragma unroll
-                for (int d = 0; d < 9; ++d) Rk[d] = liR[j][d];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) pk[d] = liP[j][d];
-#pragma unroll
-                for (int c = 0; c < 10; ++c) {
-                    double lin[3], ang[3], t[3];
-                    rot(Rk, B[c], lin);
-                    rot(Rk, B[c] + 3, ang);
-                    cross3(pk, lin, t);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        B[c][d] = lin[d];
-                        B[c][3 + d] = ang[d] + t[d];
-                    }
-                }
-            }
-        }
-        // ---- Ia / fv / fs / off columns
-        if (fric || actin || offs) {
-            if (mode == FIGH_MODE_JOINT_TORQUE) {
-                for (int k = 0; k < nl; ++k) {  // own row only (regressor.py:55-70)
-                    double *row = W + ((long)k * N + i) * ldw + 14 * k;
-                    if (actin) row[10] = ai[k];
-                    if (fric) {
-                        row[11] = vi[k];
-                        row[12] = sgn(vi[k]);
-                    }
-                    if (offs) row[13] = 1.0;
-                }
-            } else {
-                for (int c = 0; c < 6; ++c)  // all six rows, every link (regressor.py:142-169)
-                    for (int k = 0; k < nl; ++k) {
-                        double *row = W + ((long)c * N + i) * ldw + 14 * k;
-                        if (actin) row[10] = ai[k];
-                        if (fric) {
-                            row[11] = vi[k];
-                            row[12] = sgn(vi[k]);
-                        }
-                        if (offs) row[13] = 1.0;
-                    }
-            }
-        }
-        if (flags & FIGH_FLAG_TX40) {
-            const double sc = sgn(vi[4] + vi[5]);
-            double *r5 = W + ((long)4 * N + i) * ldw + 14 * nl, *r6 = W + ((long)5 * N + i) * ldw + 14 * nl;
-            r5[0] = ai[5]; r5[1] = vi[5]; r5[2] = sc;
-            r6[0] = ai[4]; r6[1] = vi[4]; r6[2] = sc;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void coupling_tx40_kernel(const long N, const int nv, const double *__restrict__ v,
                                                             const double *__restrict__ a, double *__restrict__ out) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < 6 * N; e += (long)gridDim.x * blockDim.x) {
@@ -612,25 +354,6 @@ static int launch_chain(const figh_model_s *m, int flags, long N, const double *
         hipLaunchKernelGGL((regressor_chain_kernel<NJ, TX40, false>), dim3((unsigned)grid), dim3(64), lds, stream(), P,
                            flags, N, q, v, a, W, ldw, vec_ok, nullptr);
     }
-    FIGH_HIP(hipGetLastError());
-    return FIGH_OK;
-}
-
-template <int MAXJ>
-static int launch_tree(const figh_model_s *m, int mode, int flags, int ft_mask, long N, const double *q,
-                       const double *v, const double *a, double *W, long ldw, int rows_per_sample, int ncols) {
-    // scatter kernel: W starts as zeros (non-ancestor link blocks and disabled columns stay 0)
-    if (ldw == ncols) {
-        FIGH_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)rows_per_sample * N * ldw, stream()));
-    } else {
-        FIGH_HIP(hipMemset2DAsync(W, sizeof(double) * ldw, 0, sizeof(double) * ncols, (size_t)rows_per_sample * N,
-                                  stream()));
-    }
-    long blocks = (N + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    ProfileScope scope("regressor_tree");
-    hipLaunchKernelGGL((regressor_tree_kernel<MAXJ>), dim3((unsigned)blocks), dim3(256), 0, stream(), m->dev, mode,
-                       flags, ft_mask, N, q, v, a, W, ldw);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }
@@ -702,14 +425,35 @@ extern "C" int figh_regressor_build(figh_model_t model, int mode, int flags, int
         }
         return rc;
     }
-    if (h.njoints <= 8) {
-        rc = launch_tree<8>(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_W, ldw, rps, ncols);
-    } else if (h.njoints <= 32) {
-        rc = launch_tree<32>(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_W, ldw, rps, ncols);
-    } else {
-        rc = launch_tree<kMaxJoints>(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_W, ldw, rps, ncols);
-    }
+    int colsq_done = 0;
+    rc = launch_regressor_tree(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_W, ldw, ncols, 14, d_colsq, &colsq_done);
     if (rc) return rc;
+    if (colsq_done) return FIGH_OK;
     if (d_colsq) return figh_colsq(d_W, (int64_t)rps * N, ncols, ldw, d_colsq);
     return FIGH_OK;
+}
+
+// Link-padded form of figh_regressor_build for W that stays on the device (see figh.h): 16 columns per link.
+extern "C" int figh_regressor_build_padded(figh_model_t model, int mode, int flags, int ft_mask, int64_t N,
+                                           const double *d_q, const double *d_v, const double *d_a, double *d_W,
+                                           int64_t ldw, double *d_colsq) {
+    int rps = 0, ncols = 0;
+    if (int rc = figh_regressor_shape(model, mode, flags, &rps, &ncols)) return rc;
+    FIGH_REQUIRE(N >= 0, "N < 0");
+    FIGH_REQUIRE(d_q && d_v && d_a && (d_W || d_colsq), "NULL device pointer");
+    FIGH_REQUIRE(!(model->is_chain && mode == FIGH_MODE_JOINT_TORQUE) && !(flags & FIGH_FLAG_TX40),
+                 "the link-padded layout is for tree models (chains are written as dense row tiles)");
+    const DevModel &h = model->host;
+    if (mode == FIGH_MODE_EXT_WRENCH) {
+        FIGH_REQUIRE((ft_mask & ~63) == 0, "Please enter valid parameters");  // regressor.py:140
+        if (flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA))
+            FIGH_REQUIRE(h.nlinks <= h.nv, "external-wrench friction/inertia columns need njoints-1 <= nv");
+    }
+    if (int rc = ensure_device()) return rc;
+    if (N == 0) {
+        if (d_colsq) FIGH_HIP(hipMemsetAsync(d_colsq, 0, sizeof(double) * ncols, stream()));
+        return FIGH_OK;
+    }
+    int done = 0;
+    return launch_regressor_tree(model, mode, flags & 7, ft_mask, N, d_q, d_v, d_a, d_W, ldw, ncols, 16, d_colsq, &done);
 }

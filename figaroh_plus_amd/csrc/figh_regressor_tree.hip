@@ -1,0 +1,717 @@
+// K1' -- regressor assembly for kinematic TREES (TIAGo, TALOS, human; free-flyer, prismatic and continuous joints;
+// external-wrench mode) on gfx950.
+//
+// Replaces, for every model the chain kernel (figh_regressor.hip) does not take, the per-sample Python loop around
+// pin.computeJointTorqueRegressor and the scatter / friction / permutation statements of build_regressor_basic
+// (src/figaroh/tools/regressor.py:45-87 joint torques, :89-192 external wrench).  Output in the reference's layout:
+// row r = rb*N + i (row block rb = dof index or wrench component), 14 columns per link in FIGAROH order.
+//
+// Design (one sample per lane, 64 consecutive samples per wavefront):
+//   * TAPE.  The host flattens the work for (model, mode, flags, ft_mask) into a short program of wave-uniform ops --
+//     RESET / FETCH joint inputs / STEP joint / EMIT link segment / ZERO column run -- read through the scalar cache.
+//     Joints are numbered depth-first (Pinocchio), so a walk needs ONE current state per lane; where it backs up to a
+//     branch point (TALOS: 4 times, human: 5) the path from the root is simply stepped again.  No per-joint arrays, no
+//     scratch: the state is the spatial velocity / acceleration of the current link (12 doubles) plus
+//       - external wrench on a free-flyer root (one walk, six rows per link): the placement of the link in the
+//         root-joint frame (12 doubles); row c is J_c^T B with J_c = unit twist c of the root frame seen from the link,
+//       - otherwise (one walk per row block): the motion axis J of the row's joint seen from the link (6 doubles),
+//         pushed down the subtree (J <- liMi^-1 J).
+//     The ten inertial entries of a (row, link) pair are J^T bodyRegressor(v, a) in closed form (figh_spatial.h) -- no
+//     6 x 10 body regressor is formed or carried up the chain.
+//   * FULL CACHE LINES, NO MEMSET.  Every (row block, link) segment is written exactly once: a computed segment goes
+//     through a 64 x LS LDS tile (lane = sample writes its row; the wave then streams the tile out with 16-byte buffer
+//     stores, consecutive lanes along a row segment), structural zeros (links outside the subtree, massless links) are
+//     streamed from registers as long runs.  The old kernel zero-filled all of W first (88.7 GB for TALOS) and then
+//     scattered 8-byte stores.  Measured on the TALOS / human shapes (tools/tree_kernel_bench.py, store-only tapes): the
+//     reference's 112-byte link segments (LS = 14) reach 2.3-2.6 TB/s whatever the order -- rows of W are not line
+//     aligned and every 128-byte line is shared by two links; 8-link runs reach 3.2 TB/s (rows not aligned) / 5.7 TB/s
+//     (aligned), whole contiguous rows 6.0-6.8 TB/s: a store instruction has to cover whole cache lines.  Hence the
+//     LINK-PADDED layout (LS = 16: columns 14, 15 of every link are zero, leading dimension a multiple of 16 doubles):
+//     every row segment is exactly one aligned 128-byte line, 4.4-5.0 TB/s of algorithmic bytes with one link per flush.
+//     The device-resident pipeline and the streamed entry points use it for their private W (figh_tsqr takes a column
+//     list anyway); the drop-in functions, which hand W to the caller, keep the reference's layout.
+//   * COLUMN NORMS FUSED.  In the stream-out a lane always handles the same column pair of the group, so diag(W^T W)
+//     costs two FMAs per 16 bytes; the sums are folded per group in fixed order (bit-reproducible) into per-wave column
+//     sums in LDS.  STORE = false: the norms alone (pass 1 of the streamed entry points): same arithmetic, no W at all.
+//   * ONE DRAIN PER FIVE JOINTS.  Loads and stores retire through one in-order counter on this hardware, so waiting for
+//     a load issued after a store also waits for the store's acknowledgement; the joint inputs q, qd, qdd are therefore
+//     fetched five joints at a time (FETCH) instead of inside every STEP.
+//
+// HBM-bound: algorithmic bytes per sample = 8 (nq + 2 nv) read + 8 rows_per_sample ncols written (SURVEY 8d:
+// TIAGo 65 168 B, TALOS 23 096 B, human 27 968 B).
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "figh_internal.h"
+#include "figh_spatial.h"
+#include "figh_wave.h"
+
+namespace figh {
+
+enum : int32_t { OP_RESET = 0, OP_STEP = 1, OP_EMIT = 2, OP_ZERO = 3, OP_TX40 = 4, OP_FETCH = 5 };
+// STEP flags (field b): bit 0 = the row's joint (J starts here), bits 4..6 = dof inside the joint (free-flyer),
+// bits 8.. = FETCH slot
+enum : int32_t { STEP_JSTART = 1 };
+// EMIT flags (field c)
+enum : int32_t { EMIT_INERT = 1, EMIT_EXTRA = 2, EMIT_OWN = 4, EMIT_FLUSH = 8 };
+constexpr int kFetch = 5;  // joints per FETCH group (the five payload fields of an op)
+
+struct TapeOp {
+    int32_t op, a, b, c, d, e;
+};
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Stream one link segment -- the tile, 64 rows x LS doubles -- to rows rowbase .. + nvalid - 1, columns col0 .. col0 + LS - 1
+// of W and/or add its squares to the wave's column sums.  LS = 16: 8 lanes per row, every store instruction writes 8
+// whole 128-byte lines; LS = 14: 7 lanes per 112-byte row segment (63 lanes active).
+template <int LS, bool STORE, bool COLSQ>
+__device__ __forceinline__ void flush_tile(const double *__restrict__ tile, double *__restrict__ red,
+                                           double *__restrict__ colacc, const int lane, const int nvalid,
+                                           double *__restrict__ W, const long ldw, const unsigned ldw8, const long rowbase,
+                                           const int col0) {
+    constexpr int CP = LS / 2, RPI = 64 / CP;  // 16-byte chunks per row, rows per store instruction
+    const int rg = lane / CP, ch = lane - rg * CP;
+    const bool active = rg < RPI;
+    double acc0 = 0.0, acc1 = 0.0;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(W + rowbase * ldw + col0, (short)0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)rg * ldw8 + 16u * (unsigned)ch;
+    if (active) {
+#pragma unroll
+        for (int it = 0; it < (64 + RPI - 1) / RPI; ++it) {
+            const int row = RPI * it + rg;
+            if (row < nvalid) {
+                const double2 x = *reinterpret_cast<const double2 *>(tile + row * LS + 2 * ch);
+                if constexpr (COLSQ) {
+                    acc0 = fma(x.x, x.x, acc0);
+                    acc1 = fma(x.y, x.y, acc1);
+                }
+                if constexpr (STORE) {
+                    u32x4 d;
+                    d[0] = (unsigned)__double2loint(x.x);
+                    d[1] = (unsigned)__double2hiint(x.x);
+                    d[2] = (unsigned)__double2loint(x.y);
+                    d[3] = (unsigned)__double2hiint(x.y);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, (unsigned)(RPI * it) * ldw8, 0);
+                }
+            }
+        }
+    }
+    if constexpr (COLSQ) {  // fold the row groups in fixed order: bit-reproducible
+        red[2 * lane] = active ? acc0 : 0.0;
+        red[2 * lane + 1] = active ? acc1 : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < CP) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < RPI; ++r) {
+                s0 += red[2 * (CP * r + lane)];
+                s1 += red[2 * (CP * r + lane) + 1];
+            }
+            colacc[col0 + 2 * lane] += s0;
+            colacc[col0 + 2 * lane + 1] += s1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// zeros to rows rowbase .. + nvalid - 1, columns c0 .. c0 + w - 1 (magic = ceil(2^32 / chunks per row))
+template <bool VEC2>
+__device__ __forceinline__ void stream_zeros(const int lane, const int nvalid, double *__restrict__ W, const long ldw,
+                                             const unsigned ldw8, const long rowbase, const int c0, const int w,
+                                             const unsigned magic2, const unsigned magic1) {
+    if constexpr (VEC2) {
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(W + rowbase * ldw + c0, (short)0, 0x7fffffff, 0x00020000);
+        const unsigned ch = (unsigned)w >> 1, total = (unsigned)nvalid * ch;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (unsigned id = (unsigned)lane; id < total; id += 64u) {
+            const unsigned row = __umulhi(id, magic2);
+            const unsigned k = id - row * ch;
+            __builtin_amdgcn_raw_buffer_store_b128(z, rs, row * ldw8 + 16u * k, 0u, 0);
+        }
+    } else {
+        const unsigned total = (unsigned)nvalid * (unsigned)w;
+        for (unsigned id = (unsigned)lane; id < total; id += 64u) {
+            const unsigned row = __umulhi(id, magic1);
+            const unsigned k = id - row * (unsigned)w;
+            W[(rowbase + row) * ldw + c0 + k] = 0.0;
+        }
+    }
+}
+
+// LS: columns per link in W (14 = the reference's layout; 16 = link-padded, one 128-byte line per row segment).
+// EXTFF: external wrench on a free-flyer root -- one walk, state = placement of the current link in the root-joint frame,
+// six rows per link; otherwise the row's joint axis is carried down the subtree, one walk per row block.
+// VEC2: 16-byte stores.  STORE = false: column norms only.
+template <int LS, bool EXTFF, bool VEC2, bool STORE, bool COLSQ>
+__global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__restrict__ M,
+                                                            const TapeOp *__restrict__ tape, const int ntape,
+                                                            const int flags, const long N,
+                                                            const double *__restrict__ q, const double *__restrict__ v,
+                                                            const double *__restrict__ a, double *__restrict__ W,
+                                                            const long ldw, const int ncols_int,
+                                                            double *__restrict__ colsq_part) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tile = lds;           // 64 x LS
+    double *red = lds + 64 * LS;  // 64 x 2
+    double *colacc = red + 128;   // ncols_int (COLSQ): column sums in the kernel's own (LS-strided) numbering
+    const int lane = threadIdx.x;
+    const unsigned ldw8 = 8u * (unsigned)ldw;
+    const int nq = M->nq, nv = M->nv;
+    const bool fric = flags & FIGH_FLAG_FRICTION, actin = flags & FIGH_FLAG_ACT_INERTIA, offs = flags & FIGH_FLAG_OFFSET;
+    if constexpr (COLSQ) {
+        for (int e = lane; e < ncols_int; e += 64) colacc[e] = 0.0;
+    }
+    if constexpr (LS == 16) {  // the two padding columns of the tile are written once
+        tile[16 * lane + 14] = 0.0;
+        tile[16 * lane + 15] = 0.0;
+    }
+    const double g0 = M->gravity[0], g1 = M->gravity[1], g2 = M->gravity[2];
+    const long ntiles = (N + 63) / 64;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long i0 = t * 64;
+        const int nvalid = (int)((N - i0) < 64 ? (N - i0) : 64);
+        const long i = i0 + (lane < nvalid ? lane : nvalid - 1);
+        const double *qi = q + i * nq, *vi = v + i * nv, *ai = a + i * nv;
+        // state of the current link
+        double V[6] = {0, 0, 0, 0, 0, 0}, A[6] = {-g0, -g1, -g2, 0, 0, 0};
+        double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};  // EXTFF: link -> root-joint frame
+        double Jl[3] = {0, 0, 0}, Ja[3] = {0, 0, 0};                    // otherwise: the row's joint axis, link frame
+        bool jactive = false;
+        // inputs of the coming single-dof joints (FETCH): q (cos q for a continuous joint), sin q, qd, qdd
+        double sq0[kFetch], sq1[kFetch], sqd[kFetch], sqdd[kFetch];
+#pragma unroll
+        for (int s = 0; s < kFetch; ++s) sq0[s] = sq1[s] = sqd[s] = sqdd[s] = 0.0;
+        double last_qd = 0.0, last_qdd = 0.0;  // of the joint stepped last (Ia / fv / fs of its own row)
+        for (int pcnt = 0; pcnt < ntape; ++pcnt) {
+            const int op = tape[pcnt].op, oa = tape[pcnt].a, ob = tape[pcnt].b, oc = tape[pcnt].c, od = tape[pcnt].d,
+                      oe = tape[pcnt].e;
+            if (op == OP_STEP) {
+                // ---- forward step onto joint k (restates the first loop of pinocchio::computeJointTorqueRegressor)
+                const int k = oa;
+                const int jt = M->jtype[k], iq = M->idx_q[k], iv = M->idx_v[k];
+                const double ax[3] = {M->axis[k][0], M->axis[k][1], M->axis[k][2]};
+                double jq0 = 0.0, jq1 = 0.0, jqd = 0.0, jqdd = 0.0;
+                {
+                    const int slot = ob >> 8;
+#pragma unroll
+                    for (int s = 0; s < kFetch; ++s)
+                        if (s == slot) {
+                            jq0 = sq0[s];
+                            jq1 = sq1[s];
+                            jqd = sqd[s];
+                            jqdd = sqdd[s];
+                        }
+                }
+                last_qd = jqd;
+                last_qdd = jqdd;
+                double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0}, vj[6] = {0, 0, 0, 0, 0, 0},
+                       aj[6] = {0, 0, 0, 0, 0, 0};
+                if (jt == FIGH_JT_REVOLUTE || jt == FIGH_JT_CONTINUOUS) {
+                    double s, c;
+                    if (jt == FIGH_JT_REVOLUTE) {
+                        sincos(jq0, &s, &c);
+                    } else {
+                        c = jq0;
+                        s = jq1;
+                    }
+                    rodrigues(ax, c, s, Rj);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        vj[3 + d] = ax[d] * jqd;
+                        aj[3 + d] = ax[d] * jqdd;
+                    }
+                } else if (jt == FIGH_JT_PRISMATIC) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        pj[d] = ax[d] * jq0;
+                        vj[d] = ax[d] * jqd;
+                        aj[d] = ax[d] * jqdd;
+                    }
+                } else {  // free-flyer: q = [p, qx qy qz qw], v in the joint's local frame (read here: once per walk)
+                    const double x = qi[iq + 3], y = qi[iq + 4], z = qi[iq + 5], ww = qi[iq + 6];
+                    Rj[0] = 1 - 2 * (y * y + z * z); Rj[1] = 2 * (x * y - z * ww); Rj[2] = 2 * (x * z + y * ww);
+                    Rj[3] = 2 * (x * y + z * ww); Rj[4] = 1 - 2 * (x * x + z * z); Rj[5] = 2 * (y * z - x * ww);
+                    Rj[6] = 2 * (x * z - y * ww); Rj[7] = 2 * (y * z + x * ww); Rj[8] = 1 - 2 * (x * x + y * y);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) pj[d] = qi[iq + d];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) {
+                        vj[d] = vi[iv + d];
+                        aj[d] = ai[iv + d];
+                    }
+                }
+                double Rk[9], pk[3];  // liMi = placement * M_joint(q)
+                matmul3(M->placement[k], Rj, Rk);
+                rot(M->placement[k], pj, pk);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) pk[d] += M->placement[k][9 + d];
+                double t1[3], t2[3], Vk[6], Ak[6];
+                cross3(pk, V + 3, t1);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) t2[d] = V[d] - t1[d];
+                rotT(Rk, t2, Vk);
+                rotT(Rk, V + 3, Vk + 3);
+                cross3(pk, A + 3, t1);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) t2[d] = A[d] - t1[d];
+                rotT(Rk, t2, Ak);
+                rotT(Rk, A + 3, Ak + 3);
+#pragma unroll
+                for (int d = 0; d < 6; ++d) Vk[d] += vj[d];
+                double c1[3], c2[3], c3[3];  // Vk x vj
+                cross3(Vk + 3, vj, c1);
+                cross3(Vk, vj + 3, c2);
+                cross3(Vk + 3, vj + 3, c3);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    Ak[d] += aj[d] + c1[d] + c2[d];
+                    Ak[3 + d] += aj[3 + d] + c3[d];
+                }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                    V[d] = Vk[d];
+                    A[d] = Ak[d];
+                }
+                if constexpr (EXTFF) {
+                    if (ob & STEP_JSTART) {  // the root joint: its frame is where the wrench is expressed
+#pragma unroll
+                        for (int d = 0; d < 9; ++d) Rc[d] = (d % 4 == 0) ? 1.0 : 0.0;
+                        pc[0] = pc[1] = pc[2] = 0.0;
+                    } else {
+                        double Rn[9], pn[3];
+                        matmul3(Rc, Rk, Rn);
+                        rot(Rc, pk, pn);
+#pragma unroll
+                        for (int d = 0; d < 9; ++d) Rc[d] = Rn[d];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) pc[d] += pn[d];
+                    }
+                } else {
+                    if (ob & STEP_JSTART) {  // the row's own joint: the axis of its dof, in its own frame
+                        const bool pris = jt == FIGH_JT_PRISMATIC;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            Jl[d] = pris ? ax[d] : 0.0;
+                            Ja[d] = pris ? 0.0 : ax[d];
+                        }
+                        jactive = true;
+                    } else if (jactive) {  // push the axis one link down: J <- liMi^-1 J
+                        double nJl[3], nJa[3];
+                        cross3(pk, Ja, t1);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) t2[d] = Jl[d] - t1[d];
+                        rotT(Rk, t2, nJl);
+                        rotT(Rk, Ja, nJa);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            Jl[d] = nJl[d];
+                            Ja[d] = nJa[d];
+                        }
+                    }
+                }
+            } else if (op == OP_EMIT) {
+                // ---- the segment of link oa: EXTFF in all six row blocks (od = components with inertial entries),
+                // otherwise in row block ob
+                const int b = oa, col0 = LS * (b - 1);
+                double ex[4] = {0.0, 0.0, 0.0, 0.0};
+                if (oc & EMIT_EXTRA) {  // regressor.py:55-70 (own row) / :142-169 (all six rows): Ia fv fs off of link b
+                    // joint-torque mode writes them on the link's own row, right after its STEP: dof b - 1 is that joint
+                    const bool own = oc & EMIT_OWN;
+                    if (actin) ex[0] = own ? last_qdd : ai[b - 1];
+                    if (fric) {
+                        const double vv = own ? last_qd : vi[b - 1];
+                        ex[1] = vv;
+                        ex[2] = sgn(vv);
+                    }
+                    if (offs) ex[3] = 1.0;
+                }
+                double accv[3];
+                {
+                    double tt[3];
+                    cross3(V + 3, V, tt);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) accv[d] = A[d] + tt[d];
+                }
+                double *my = tile + LS * lane;
+#pragma unroll 1
+                for (int c = 0; c < (EXTFF ? 6 : 1); ++c) {
+                    double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (EXTFF) {
+                        if ((od >> c) & 1) {  // unit twist c of the root-joint frame, seen from the link
+                            double jl[3], ja[3];
+                            if (c < 3) {
+                                jl[0] = Rc[3 * c];
+                                jl[1] = Rc[3 * c + 1];
+                                jl[2] = Rc[3 * c + 2];
+                                ja[0] = ja[1] = ja[2] = 0.0;
+                            } else {
+                                const int kk = c - 3;
+                                ja[0] = Rc[3 * kk];
+                                ja[1] = Rc[3 * kk + 1];
+                                ja[2] = Rc[3 * kk + 2];
+                                double tt[3];  // Jl = Rc^T (e_k x pc)
+                                tt[0] = kk == 0 ? 0.0 : (kk == 1 ? pc[2] : -pc[1]);
+                                tt[1] = kk == 0 ? -pc[2] : (kk == 1 ? 0.0 : pc[0]);
+                                tt[2] = kk == 0 ? pc[1] : (kk == 1 ? -pc[0] : 0.0);
+                                rotT(Rc, tt, jl);
+                            }
+                            axis_times_body_regressor(jl, ja, accv, A + 3, V + 3, o);
+                        }
+                    } else {
+                        if (oc & EMIT_INERT) axis_times_body_regressor(Jl, Ja, accv, A + 3, V + 3, o);
+                    }
+#pragma unroll
+                    for (int d = 0; d < 10; ++d) my[d] = o[d];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) my[10 + d] = ex[d];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const long rowbase = (long)(EXTFF ? c : ob) * N + i0;
+                    if constexpr (VEC2) {
+                        flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0);
+                    } else {  // odd column count / unaligned W: plain 8-byte stores, no fused norms
+                        for (int id = lane; id < nvalid * 14; id += 64) {
+                            const int row = id / 14, col = id - 14 * row;
+                            W[(rowbase + row) * ldw + col0 + col] = tile[row * LS + col];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else if (op == OP_ZERO) {
+                if constexpr (STORE)
+                    stream_zeros<VEC2>(lane, nvalid, W, ldw, ldw8, (long)oa * N + i0, ob, oc, (unsigned)od, (unsigned)oe);
+            } else if (op == OP_FETCH) {
+                const int js[kFetch] = {oa, ob, oc, od, oe};
+#pragma unroll
+                for (int s = 0; s < kFetch; ++s)
+                    if (js[s] > 0) {
+                        const int iq = M->idx_q[js[s]], iv = M->idx_v[js[s]];
+                        sq0[s] = qi[iq];
+                        sq1[s] = M->jtype[js[s]] == FIGH_JT_CONTINUOUS ? qi[iq + 1] : 0.0;
+                        sqd[s] = vi[iv];
+                        sqdd[s] = ai[iv];
+                    }
+            } else if (op == OP_RESET) {
+#pragma unroll
+                for (int d = 0; d < 6; ++d) V[d] = 0.0;
+                A[0] = -g0; A[1] = -g1; A[2] = -g2; A[3] = A[4] = A[5] = 0.0;
+#pragma unroll
+                for (int d = 0; d < 9; ++d) Rc[d] = (d % 4 == 0) ? 1.0 : 0.0;
+                pc[0] = pc[1] = pc[2] = 0.0;
+                jactive = false;
+            } else {  // OP_TX40 (regressor.py:198-227, fused): columns 14 nl .. + 2 on the six joint rows
+                if constexpr (STORE) {
+                    if (lane < nvalid) {
+                        const double sc = sgn(vi[4] + vi[5]);
+                        for (int r = 0; r < 6; ++r) {
+                            double *row = W + ((long)r * N + i) * ldw + oa;
+                            row[0] = r == 4 ? ai[5] : (r == 5 ? ai[4] : 0.0);
+                            row[1] = r == 4 ? vi[5] : (r == 5 ? vi[4] : 0.0);
+                            row[2] = (r == 4 || r == 5) ? sc : 0.0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (COLSQ) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = lane; e < ncols_int; e += 64) colsq_part[(long)blockIdx.x * ncols_int + e] = colacc[e];
+    }
+}
+
+// partial[b][LS l + s] -> out[14 l + s]: one workgroup per reference column, strided partial sums + LDS tree (fixed
+// order: deterministic)
+__global__ __launch_bounds__(256) void reduce_tree_partials_kernel(const double *__restrict__ part, int nblocks,
+                                                                   int ncols_int, int ls, double *__restrict__ out) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x;
+    const int ci = (c / 14) * ls + c % 14;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long)b * ncols_int + ci];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sm[0];
+}
+
+// ---------------------------------------------------------------------------------------------- tape builder (host)
+unsigned magic_for(unsigned d) { return d ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; }
+
+struct TapeBuilder {
+    const DevModel &h;
+    std::vector<TapeOp> ops;
+    explicit TapeBuilder(const DevModel &m) : h(m) {}
+    void push(int op, int a = 0, int b = 0, int c = 0, int d = 0, int e = 0) { ops.push_back({op, a, b, c, d, e}); }
+    void zero(int rowblock, int col0, int w) {
+        if (w <= 0) return;
+        push(OP_ZERO, rowblock, col0, w, (int)magic_for((unsigned)w / 2), (int)magic_for((unsigned)w));
+    }
+    std::vector<int> path_to(int k) const {  // joints root -> k (universe excluded)
+        std::vector<int> p;
+        for (int j = k; j > 0; j = h.parents[j]) p.insert(p.begin(), j);
+        return p;
+    }
+    int subtree_end(int j) const {  // joints j .. end-1 form the subtree of j (depth-first numbering)
+        int e = j + 1;
+        while (e < h.njoints) {
+            int k = e;
+            while (k > j) k = h.parents[k];
+            if (k != j) break;
+            ++e;
+        }
+        return e;
+    }
+};
+
+// Insert the FETCH ops: the single-dof STEPs are grouped by kFetch in tape order, each group's joint inputs are loaded
+// by one FETCH in front of its first STEP, and every STEP learns its slot (bits 8.. of its flags field).
+std::vector<TapeOp> with_fetches(const DevModel &h, const std::vector<TapeOp> &in) {
+    std::vector<TapeOp> out;
+    out.reserve(in.size() + in.size() / kFetch + 1);
+    auto fetched = [&](const TapeOp &op) { return op.op == OP_STEP && h.jtype[op.a] != FIGH_JT_FREEFLYER; };
+    size_t i = 0;
+    while (i < in.size()) {
+        int js[kFetch] = {0, 0, 0, 0, 0};
+        int cnt = 0;
+        size_t j = i;
+        for (; j < in.size() && cnt < kFetch; ++j)
+            if (fetched(in[j])) js[cnt++] = in[j].a;
+        if (cnt == 0) {  // no step left: copy the rest
+            out.insert(out.end(), in.begin() + i, in.end());
+            break;
+        }
+        size_t first = i;
+        while (!fetched(in[first])) ++first;
+        out.insert(out.end(), in.begin() + i, in.begin() + first);
+        out.push_back({OP_FETCH, js[0], js[1], js[2], js[3], js[4]});
+        int slot = 0;
+        for (size_t k = first; k < j; ++k) {
+            TapeOp op = in[k];
+            if (fetched(op)) op.b |= (slot++) << 8;
+            out.push_back(op);
+        }
+        i = j;
+    }
+    return out;
+}
+
+// external wrench, free-flyer root: one walk over the tree, six row segments per link (ls = columns per link in W)
+std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, int ls) {
+    TapeBuilder T(h);
+    const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
+    int prev = 0, zero_from = -1;
+    auto flush_zero = [&](int upto_link) {  // links zero_from .. upto_link-1 (1-based joints) are all-zero segments
+        if (zero_from < 0) return;
+        for (int c = 0; c < 6; ++c) T.zero(c, ls * (zero_from - 1), ls * (upto_link - zero_from));
+        zero_from = -1;
+    };
+    T.push(OP_RESET);
+    for (int b = 1; b < h.njoints; ++b) {
+        if (h.parents[b] != prev) {
+            T.push(OP_RESET);
+            for (int k : T.path_to(h.parents[b])) T.push(OP_STEP, k, k == 1 ? STEP_JSTART : 0);
+        }
+        T.push(OP_STEP, b, b == 1 ? STEP_JSTART : 0);
+        prev = b;
+        const int inert = h.body_mask[b] ? (ft_mask & 63) : 0;
+        if (inert || extras) {
+            flush_zero(b);
+            T.push(OP_EMIT, b, 0, (inert ? EMIT_INERT : 0) | (extras ? EMIT_EXTRA : 0), inert);
+        } else if (zero_from < 0) {
+            zero_from = b;
+        }
+    }
+    flush_zero(h.njoints);
+    return with_fetches(h, T.ops);
+}
+
+// One row block per dof.  Joint-torque mode: every joint is single-dof and has its row.  External wrench on a fixed
+// base: rows = the first six joints; inertial entries only for links with mass and components in ft_mask, Ia / fv / fs /
+// off on all six rows of every link (regressor.py:142-169).
+std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int ft_mask, int ls) {
+    TapeBuilder T(h);
+    const bool ext = mode == FIGH_MODE_EXT_WRENCH;
+    const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
+    const int nrows = ext ? 6 : h.nv;
+    const int nl = h.nlinks;
+    for (int row = 0; row < nrows; ++row) {
+        int j = 0;  // the joint that owns dof `row`
+        for (int k = 1; k < h.njoints; ++k)
+            if (h.idx_v[k] == row) j = k;
+        const bool row_inert = j > 0 && (!ext || ((ft_mask >> row) & 1));
+        const int s0 = j > 0 ? j : nl + 1, s1 = j > 0 ? T.subtree_end(j) : nl + 1;  // links s0 .. s1-1 = subtree
+        int prev = -1, zero_from = -1;
+        auto flush_zero = [&](int upto_link) {
+            if (zero_from < 0) return;
+            T.zero(row, ls * (zero_from - 1), ls * (upto_link - zero_from));
+            zero_from = -1;
+        };
+        for (int b = 1; b <= nl; ++b) {
+            const bool in_sub = b >= s0 && b < s1;
+            const bool inert = row_inert && in_sub && (!ext || h.body_mask[b]);
+            const bool extra = extras && (ext || b == j);
+            if (in_sub && row_inert) {  // the walk over the subtree keeps the state current even for massless links
+                if (b == j || h.parents[b] != prev) {
+                    T.push(OP_RESET);
+                    for (int k : T.path_to(h.parents[b])) T.push(OP_STEP, k, k == j ? STEP_JSTART : 0);
+                }
+                T.push(OP_STEP, b, b == j ? STEP_JSTART : 0);
+                prev = b;
+            }
+            if (inert || extra) {
+                flush_zero(b);
+                T.push(OP_EMIT, b, row,
+                       (inert ? EMIT_INERT : 0) | (extra ? EMIT_EXTRA : 0) | ((!ext && b == j && row_inert) ? EMIT_OWN : 0));
+            } else if (zero_from < 0) {
+                zero_from = b;
+            }
+        }
+        flush_zero(nl + 1);
+    }
+    if (flags & FIGH_FLAG_TX40) T.push(OP_TX40, ls * nl);
+    return with_fetches(h, T.ops);
+}
+
+struct DeviceTape {
+    TapeOp *dev = nullptr;
+    int n = 0;
+    bool extff = false;
+};
+std::map<std::vector<long>, DeviceTape> g_tapes;  // (model handle, mode, flags, ft_mask, ls) -> tape
+
+}  // namespace
+
+// internal: rows of W for a tree model.  ls = columns per link in W: 14 (the reference's layout, ncols = 14 nlinks [+ 3])
+// or 16 (link-padded: columns 14, 15 of every link are zero, every row segment is one 128-byte line; needs ldw % 16 == 0
+// and a 128-byte aligned W).  W == nullptr: column norms only.  d_colsq (nullable) receives diag(W^T W) in the
+// reference's column numbering; *colsq_done = 0 when the norms could not be fused (odd column count / unaligned W: the
+// caller runs figh_colsq).
+int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mask, long N, const double *q,
+                          const double *v, const double *a, double *W, long ldw, int ncols, int ls, double *d_colsq,
+                          int *colsq_done) {
+    const DevModel &h = m->host;
+    const bool store = W != nullptr;
+    FIGH_REQUIRE(store || d_colsq, "nothing to compute");
+    FIGH_REQUIRE(ls == 14 || ls == 16, "link stride must be 14 or 16");
+    FIGH_REQUIRE(ls == 14 || !(flags & FIGH_FLAG_TX40), "the link-padded layout has no TX40 coupling columns");
+    const int ncols_int = ls * h.nlinks + ((flags & FIGH_FLAG_TX40) ? 3 : 0);
+    if (!store) ldw = ncols_int;
+    FIGH_REQUIRE(ldw >= ncols_int, "ldw smaller than the number of columns");
+    FIGH_REQUIRE(ldw < (1L << 22), "figh_regressor_build: leading dimension must be below 2^22 elements");
+    if (store && ls == 16)
+        FIGH_REQUIRE(ldw % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 128 == 0, "link-padded W must be 128-byte aligned");
+    const bool extff = mode == FIGH_MODE_EXT_WRENCH && h.jtype[1] == FIGH_JT_FREEFLYER;
+    for (int k = extff ? 2 : 1; k < h.njoints; ++k)
+        FIGH_REQUIRE(h.jtype[k] != FIGH_JT_FREEFLYER, "a free-flyer joint is only supported as the root joint of the "
+                                                      "external-wrench mode");
+    const std::vector<long> key = {(long)reinterpret_cast<uintptr_t>(m), mode, flags & (7 | FIGH_FLAG_TX40), ft_mask, ls};
+    auto it = g_tapes.find(key);
+    if (it == g_tapes.end()) {
+        std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls) : build_tape_rows(h, mode, flags, ft_mask, ls);
+#ifdef FIGH_ABLATION
+        if (const char *e = getenv("FIGH_TREE_TAPE")) {  // store-pattern ceilings: W is all zeros, timing only
+            TapeBuilder T(h);
+            const int nrows = mode == FIGH_MODE_EXT_WRENCH ? 6 : h.nv;
+            if (!strncmp(e, "zrun", 4)) {  // runs of k links, row-block-major
+                const int k = atoi(e + 4);
+                for (int r = 0; r < nrows; ++r)
+                    for (int b = 1; b <= h.nlinks; b += k)
+                        T.zero(r, ls * (b - 1), ls * (b + k - 1 <= h.nlinks ? k : h.nlinks - b + 1));
+            } else if (!strcmp(e, "zlink")) {  // one segment per (link, row block), link-major
+                for (int b = 1; b <= h.nlinks; ++b)
+                    for (int r = 0; r < nrows; ++r) T.zero(r, ls * (b - 1), ls);
+            } else {  // whole rows
+                for (int r = 0; r < nrows; ++r) T.zero(r, 0, ncols_int);
+            }
+            ops = T.ops;
+        }
+#endif
+        DeviceTape dt;
+        dt.n = (int)ops.size();
+        dt.extff = extff;
+        if (hipMalloc(&dt.dev, sizeof(TapeOp) * (ops.empty() ? 1 : ops.size())) != hipSuccess) {
+            set_error("hipMalloc(tape) failed");
+            return FIGH_ERR_ALLOC;
+        }
+        FIGH_HIP(hipMemcpy(dt.dev, ops.data(), sizeof(TapeOp) * ops.size(), hipMemcpyHostToDevice));
+        it = g_tapes.emplace(key, dt).first;
+    }
+    const DeviceTape &tp = it->second;
+    const bool vec2 = !store || ls == 16 ||
+                      ((ncols_int % 2 == 0) && (ldw % 2 == 0) && (reinterpret_cast<uintptr_t>(W) % 16 == 0));
+    const bool fuse = d_colsq != nullptr && vec2;
+    *colsq_done = fuse ? 1 : 0;
+    (void)ncols;
+    const long ntiles = (N + 63) / 64;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t lds = sizeof(double) * (64 * (size_t)ls + 128 + (size_t)(fuse ? ncols_int : 0));
+    long grid = (long)cus * 8;
+    if (grid > ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
+    double *part = nullptr;
+    if (fuse) {
+        part = static_cast<double *>(workspace(sizeof(double) * grid * ncols_int, 0));
+        if (!part) return FIGH_ERR_ALLOC;
+    }
+    ProfileScope scope("regressor_tree");
+#define FIGH_TAPE_LAUNCH(LS, E, V2, ST, C)                                                                             \
+    hipLaunchKernelGGL((regressor_tape_kernel<LS, E, V2, ST, C>), dim3((unsigned)grid), dim3(64), lds, stream(), m->dev, \
+                       tp.dev, tp.n, flags, N, q, v, a, W, ldw, ncols_int, part)
+#define FIGH_TAPE_MODES(LS, E)                                      \
+    do {                                                            \
+        if (!store) FIGH_TAPE_LAUNCH(LS, E, true, false, true);     \
+        else if (vec2 && fuse) FIGH_TAPE_LAUNCH(LS, E, true, true, true);  \
+        else if (vec2) FIGH_TAPE_LAUNCH(LS, E, true, true, false);  \
+        else FIGH_TAPE_LAUNCH(14, E, false, true, false);           \
+    } while (0)
+    if (ls == 16) {
+        if (tp.extff) FIGH_TAPE_MODES(16, true);
+        else FIGH_TAPE_MODES(16, false);
+    } else {
+        if (tp.extff) FIGH_TAPE_MODES(14, true);
+        else FIGH_TAPE_MODES(14, false);
+    }
+#undef FIGH_TAPE_MODES
+#undef FIGH_TAPE_LAUNCH
+    FIGH_HIP(hipGetLastError());
+    if (fuse) {
+        const int nref = 14 * h.nlinks;  // (TX40 tail: never fused, odd column count)
+        hipLaunchKernelGGL(reduce_tree_partials_kernel, dim3(nref), dim3(256), 0, stream(), part, (int)grid, ncols_int, ls,
+                           d_colsq);
+        FIGH_HIP(hipGetLastError());
+    }
+    return FIGH_OK;
+}
+
+void forget_tapes(const figh_model_s *m) {  // figh_model_destroy
+    for (auto it = g_tapes.begin(); it != g_tapes.end();) {
+        if (it->first[0] == (long)reinterpret_cast<uintptr_t>(m)) {
+            (void)hipFree(it->second.dev);
+            it = g_tapes.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+}  // namespace figh

@@ -23,6 +23,15 @@ __global__ __launch_bounds__(256) void vec_add_kernel(double *__restrict__ acc, 
     if (i < n) acc[i] += x[i];
 }
 
+// reference column 14 l + s -> link-padded column 16 l + s (a NULL list = all columns)
+__global__ __launch_bounds__(256) void pad_columns_kernel(const int32_t *__restrict__ in, int n, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int c = in ? in[i] : i;
+        out[i] = (c / 14) * 16 + c % 14;
+    }
+}
+
 int64_t default_chunk(int rps, int ncols) {
     // ~2 GB of W per chunk: large enough to fill the chip (2048 waves x >= 8 tiles), small next to 288 GB
     int64_t c = (int64_t)(2.0e9 / (8.0 * rps * ncols));
@@ -41,6 +50,13 @@ extern "C" int figh_regressor_colsq(figh_model_t model, int mode, int flags, int
     if (int rc = ensure_device()) return rc;
     FIGH_HIP(hipMemsetAsync(d_colsq, 0, sizeof(double) * ncols, stream()));
     if (N == 0) return FIGH_OK;
+    if (!(model->is_chain && mode == FIGH_MODE_JOINT_TORQUE && !(flags & FIGH_FLAG_GENERIC)) && !(flags & FIGH_FLAG_TX40)) {
+        // tree kernel: the norms are accumulated from the computed segments directly, W is never written (nor chunked)
+        int done = 0;
+        if (int rc = launch_regressor_tree(model, mode, flags, ft_mask, N, d_q, d_v, d_a, nullptr, 0, ncols, 16, d_colsq, &done))
+            return rc;
+        return FIGH_OK;
+    }
     if (chunk_samples == 0) chunk_samples = default_chunk(rps, ncols);
     const int64_t cs = chunk_samples < N ? chunk_samples : N;
     double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs * ncols, 8));
@@ -77,7 +93,18 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     if (chunk_samples == 0) chunk_samples = default_chunk(rps, ncols);
     const int64_t cs = chunk_samples < N ? chunk_samples : N;
     const int64_t nchunks = (N + cs - 1) / cs;
-    double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs * ncols, 8));
+    // the chunk's W is a private workspace: tree models get the link-padded layout (16 columns per link, every row
+    // segment one 128-byte line) and the caller's column list is translated to it
+    const bool padded = !(model->is_chain && mode == FIGH_MODE_JOINT_TORQUE) && !(flags & FIGH_FLAG_TX40);
+    const int64_t ldc = padded ? 16 * (int64_t)model->host.nlinks : ncols;
+    double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs * ldc, 8));
+    int32_t *d_cols = const_cast<int32_t *>(d_col_idx);
+    if (padded) {
+        d_cols = static_cast<int32_t *>(workspace(sizeof(int32_t) * (size_t)n, 9));
+        if (!d_cols) return FIGH_ERR_ALLOC;
+        hipLaunchKernelGGL(pad_columns_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), d_col_idx, n, d_cols);
+        FIGH_HIP(hipGetLastError());
+    }
     double *tc = d_tau ? static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs, 10)) : nullptr;
     // level-0 triangles of ALL chunks are stacked and the merge tree runs once (a merge is latency-bound: running it
     // per chunk cost 158 ms of the 1.24 s human pass)
@@ -109,8 +136,10 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     int64_t have = 0;
     for (int64_t lo = 0; lo < N; lo += cs) {
         const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
-        if (int rc = figh_regressor_build(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv, d_a + lo * nv, Wc,
-                                          ncols, nullptr))
+        if (int rc = padded ? figh_regressor_build_padded(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv,
+                                                          d_a + lo * nv, Wc, ldc, nullptr)
+                            : figh_regressor_build(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv,
+                                                   d_a + lo * nv, Wc, ldc, nullptr))
             return rc;
         if (d_tau)  // rows j*N + [lo, lo + nc_) of tau -> the chunk's joint-major vector (rows j*nc_ + i)
             FIGH_HIP(hipMemcpy2DAsync(tc, sizeof(double) * nc_, d_tau + lo, sizeof(double) * N, sizeof(double) * nc_, rps,
@@ -119,7 +148,7 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
         if (!first.empty() && nc_ >= 64) {
             if (int rc = figh_tsqr_hint_begin(first.data(), rps, (int64_t)rps * nc_, n, nc)) return rc;
         }
-        const int rc0 = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ncols, d_col_idx, n, tc, h_block_weight, nblocks,
+        const int rc0 = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ldc, d_cols, n, tc, h_block_weight, nblocks,
                                          stack + (size_t)have * nc * nc, per_chunk, &got, nullptr);
         figh_tsqr_hint_end();
         if (rc0) return rc0;

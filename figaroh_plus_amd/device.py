@@ -30,8 +30,12 @@ class GpuMatrix:
         return self.buf.ptr
 
     @classmethod
-    def empty(cls, rows, cols):
-        return cls(_lib.DeviceArray((max(int(rows) * int(cols), 1),), np.float64), rows, cols)
+    def empty(cls, rows, cols, ld=None):
+        """``ld``: leading dimension in elements (default ``cols``: the reference's dense layout).  Buffers that never
+        leave the device may pad it to whole 128-byte lines (16 doubles): the tree regressor kernel then writes full
+        cache lines."""
+        ld = int(cols if ld is None else ld)
+        return cls(_lib.DeviceArray((max(int(rows) * ld, 1),), np.float64), rows, cols, ld)
 
     @classmethod
     def from_host(cls, arr):
@@ -41,11 +45,15 @@ class GpuMatrix:
         return cls(_lib.DeviceArray.from_host(arr.reshape(-1)), arr.shape[0], arr.shape[1])
 
     def numpy(self):
-        assert self.ld == self.cols
-        out = np.empty((self.rows, self.cols))
-        if out.size:
-            _lib.check(_lib.load().figh_memcpy_d2h(out.ctypes.data, self.buf.ptr, out.nbytes))
-        return out
+        if self.ld == self.cols:
+            out = np.empty((self.rows, self.cols))
+            if out.size:
+                _lib.check(_lib.load().figh_memcpy_d2h(out.ctypes.data, self.buf.ptr, out.nbytes))
+            return out
+        full = np.empty((self.rows, self.ld))
+        if full.size:
+            _lib.check(_lib.load().figh_memcpy_d2h(full.ctypes.data, self.buf.ptr, full.nbytes))
+        return np.ascontiguousarray(full[:, :self.cols])
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()

@@ -192,7 +192,16 @@ class IdentificationPipeline:
         handle = self.robot.device_model()
         if self.W is None:  # HBM buffers are allocated once and reused by every step
             rows_per_sample, ncols = handle.shape(mode, flags)
-            self.W = GpuMatrix.empty(rows_per_sample * self.N, ncols)
+            # W stays in HBM.  Chains: the reference's dense layout (the chain kernel streams one contiguous run per tile).
+            # Trees: the link-padded layout of figh_regressor_build_padded -- 16 columns per link, every (row, link)
+            # segment one 128-byte line -- which K1' writes at about twice the rate; the TSQR takes a column list anyway.
+            self._padded = not (handle.is_chain() and mode == _lib.MODE_JOINT_TORQUE) and not self.coupling
+            if self._padded:
+                self.W = GpuMatrix.empty(rows_per_sample * self.N, 16 * (self.robot.model.njoints - 1))
+                self.W.ref_cols = ncols
+            else:
+                self.W = GpuMatrix.empty(rows_per_sample * self.N, ncols)
+                self.W.ref_cols = ncols
             cap = ncols + 1
             self._d_colsq = _lib.DeviceArray((ncols,), np.float64)
             self._d_idx = _lib.DeviceArray((cap,), np.int32)
@@ -201,8 +210,12 @@ class IdentificationPipeline:
             self._d_Rp = _lib.DeviceArray((cap * cap,), np.float64)
             self._d_R2 = _lib.DeviceArray((cap * cap,), np.float64)
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
-        _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
-        col_norm = ex.sum_columns(d_colsq, W.cols)
+        if self._padded:
+            _lib.regressor_build_padded(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld,
+                                        d_colsq)
+        else:
+            _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
+        col_norm = ex.sum_columns(d_colsq, W.ref_cols)
         small = col_norm < self.tol_e  # regressor.py:271-277 (NaN compares False: kept, as in the reference's loop)
         idx_e = np.flatnonzero(small).tolist()
         kept_i32 = np.flatnonzero(~small).astype(np.int32)
@@ -213,7 +226,8 @@ class IdentificationPipeline:
         with_tau = self.d_tau is not None
         nc = n + (1 if with_tau else 0)
         d_R, d_idx = self._d_R, self._d_idx
-        _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
+        dev_cols = (kept_i32 // 14) * 16 + kept_i32 % 14 if self._padded else kept_i32  # column list in W's own numbering
+        _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, dev_cols.ctypes.data, dev_cols.nbytes))
         _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R, first_cols=self._structure_hint(mode, kept_i32))
         d_stack, count = ex.stack_triangles(d_R, nc)
         if count > 1:

@@ -91,6 +91,16 @@ int figh_regressor_shape(figh_model_t model, int mode, int flags, int *rows_per_
 int figh_regressor_build(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
                          const double *d_v, const double *d_a, double *d_W, int64_t ldw, double *d_colsq);
 
+/* figh_regressor_build_padded: the same regressor for W that STAYS ON THE DEVICE (IdentificationPipeline, the streamed
+ * entry points), tree models only.  Link-padded layout: 16 columns per link -- the 14 of the reference followed by two
+ * zero columns -- so reference column 14 l + s is column 16 l + s; ldw must be a multiple of 16 (>= 16 (njoints-1)) and
+ * d_W 128-byte aligned: every (row, link) segment is then exactly one cache line and the kernel writes whole lines
+ * (4.4-5.0 TB/s against 2.3-2.6 TB/s for the 112-byte segments of the dense layout, rows of which are not line
+ * aligned).  d_W may be NULL: column norms only.  d_colsq (nullable) is in the REFERENCE's column numbering
+ * (14 (njoints-1) entries).  figh_tsqr / figh_matvec / figh_gather_cols take such a W through their column lists. */
+int figh_regressor_build_padded(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                                const double *d_v, const double *d_a, double *d_W, int64_t ldw, double *d_colsq);
+
 /* add_coupling_TX40 as a separate call (regressor.py:198-227), for callers that append the three columns
  * [Iam6 fvm6 fsm6] to an existing W: d_out is (6N x 3) row-major, rows in the same joint-major order; only the
  * rows of joints 5 and 6 are non-zero: [a6 v6 sign(v5+v6)] and [a5 v5 sign(v5+v6)].  d_v, d_a: N x nv, nv >= 6. */

@@ -49,7 +49,13 @@ def test_regressor_matches_golden(lib, golden):
     ref = g["W_small"]
     assert W.shape == ref.shape and W.dtype == np.float64
     assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
-    assert np.array_equal(W == 0, ref == 0)  # structural zeros (and sign(0) = 0) are exact
+    # structural zeros (and sign(0) = 0) are exact: wherever the reference is exactly zero, so is the kernel.  The other
+    # direction holds up to rounding residues of the REFERENCE's own arithmetic: Pinocchio's literal propagation of the
+    # 6 x 10 body regressor leaves entries of 1e-17 relative size (TIAGo: mz of two links on the prismatic torso row)
+    # where the closed-form row evaluation of the tree kernel gives an exact zero.
+    assert not W[ref == 0].any()
+    extra_zero = (W == 0) & (ref != 0)
+    assert np.abs(ref[extra_zero]).max(initial=0.0) <= 1e-15 * np.abs(ref).max()
 
 
 def test_generic_tree_kernel_on_chains(lib, golden):
