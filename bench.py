@@ -5,9 +5,11 @@ One "step" = one pass of the hot path over this rank's resident batch of synthet
 K1 regressor assembly (W materialised in the reference layout, column norms fused) -> elimination ->
 K3 Householder TSQR over the kept columns + tau -> host tail (rank decision, regrouping, beta, strings,
 phi) -> [N>1: RCCL all-reduce of column norms + all-gather of R factors].  Inputs are resident in HBM
-before the timed region.  Workload = BASELINE.json configs[1] (UR10 6-DoF, 1e6 samples per GPU: weak scaling).
+before the timed region.  Default workload = BASELINE.json configs[1] (UR10 6-DoF, 1e6 samples per GPU: weak scaling).  --config cfg3|cfg4|cfg5 runs
+the other BASELINE configs (TIAGo 1e6, TALOS 4e6, human 1e7 streamed), by default with STRONG scaling: the config's total
+sample count is sharded over the GPUs (north_star: >= 6x at 8 GPUs on the sharded configs).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfgK] [--scaling weak|strong] [--samples S]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -67,16 +69,34 @@ def cpu_baseline_fast(flat, seed, n_cpu):
                       "stage seconds %s" % (n_cpu, {k: round(x, 2) for k, x in stages.items()})}
 
 
+CONFIGS = {  # BASELINE.json configs[1..4]: (golden fixture, model, samples in the config, chunk for the streamed pass)
+    "cfg2": ("cfg2_ur10", "ur10", 1_000_000, None),
+    "cfg3": ("cfg3_tiago", "tiago", 1_000_000, None),
+    "cfg4": ("cfg4_talos", "talos", 4_000_000, None),
+    "cfg5": ("cfg5_human", "human", 10_000_000, 500_000),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=1_000_000, help="samples per GPU")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
+                    help="cfg2 (default) = the workload the metric is quoted on; cfg3-5 = the other BASELINE configs")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: --samples per GPU (default for cfg2); strong: the config's total sharded over the GPUs "
+                         "(default for cfg3-5)")
+    ap.add_argument("--samples", type=int, default=None, help="samples per GPU (weak) / in total (strong)")
     ap.add_argument("--cpu-samples", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
     args = ap.parse_args()
+
+    # the shipped library has no run-time switches; FIGH_LIB_PATH would swap in another build (tools/ A/B runs only)
+    stray = sorted(k for k in os.environ if k.startswith("FIGH_"))
+    if stray:
+        raise SystemExit("bench.py refuses to run with FIGH_* variables set: %s" % ", ".join(stray))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,8 +106,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
 
     from figaroh_plus_amd import _lib
-    from figaroh_plus_amd.dist import exchange_from_env
+    from figaroh_plus_amd.dist import exchange_from_env, shard_range
     from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
     from figaroh_plus_amd.tools.robot import Robot
 
     lib = _lib.load()
@@ -102,18 +123,30 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    with open(os.path.join(ROOT, "tests", "golden", "cfg2_ur10.json")) as f:
+    fixture, model_name, n_config, chunk = CONFIGS[args.config]
+    scaling = args.scaling or ("weak" if args.config == "cfg2" else "strong")
+    with open(os.path.join(ROOT, "tests", "golden", fixture + ".json")) as f:
         meta = json.load(f)
-    robot = Robot.from_flat("ur10")
+    robot = Robot.from_flat(model_name)
     param = meta["param"]
     params_std = dict(zip(meta["names_std"], meta["phi_ref_raw"]))
-    N = args.samples
-    rng = np.random.default_rng(20250410 + 2 + 1000 * rank)
-    q, v, a = (rng.uniform(-6, 6, (N, 6)) for _ in range(3))
-    pipe = IdentificationPipeline(robot, param, params_std=params_std, exchange=exchange)
+    if scaling == "weak":
+        N = args.samples or n_config          # per GPU
+        n_total = N * world
+    else:
+        n_total = args.samples or n_config    # sharded: contiguous sample ranges (dist.shard_range)
+        lo, hi = shard_range(n_total, rank, world)
+        N = hi - lo
+    rng = np.random.default_rng(20250410 + int(args.config[3]) + 1000 * rank)
+    if args.config == "cfg2":  # examples/ur10/identification.py:71-81
+        q, v, a = (rng.uniform(-6, 6, (N, 6)) for _ in range(3))
+    else:
+        q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
+    pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
+                                  chunk_samples=chunk)
     pipe.set_samples(q, v, a)
     phi_ref = np.array([float(x) for x in meta["phi_ref_raw"]])
-    d_tau = pipe.set_tau_from_parameters(phi_ref, noise_std=0.05, seed=rank)
+    pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config == "cfg2" else 0.0, seed=rank)
     del q, v, a
 
     out = None
@@ -130,6 +163,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     _lib.profile_enable(False)
+    dt_rank = dt
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -137,11 +171,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # sanity: the step produced the reference's structural result
-    ok = out["idx_base"] == meta_idx(meta) and out["params_base"] == meta["params_base"]
+    # sanity: the step produced the reference's structural result (cfg3 at 1e6 samples: four dependent pivots grow past
+    # TOL_QR like sqrt(N), LAPACK agrees -- DESIGN.md section 4 -- so only the eliminated columns are compared there)
+    ok = out["idx_e"] == [int(x) for x in np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))["idx_e"]]
+    if args.config != "cfg3":
+        ok = ok and out["idx_base"] == meta_idx(meta) and out["params_base"] == meta["params_base"]
     n_kept = len(out["params_r"])
     kern = {}
-    for name in ("regressor_chain", "tsqr"):
+    k1_name = "regressor_chain" if args.config == "cfg2" else "regressor_tree"
+    for name in (k1_name, "tsqr"):
         cnt, ms = _lib.profile_get(name)
         if cnt:
             kern[name] = {"launches": cnt, "avg_ms": ms / cnt}
@@ -156,66 +194,89 @@ def main():
         if cnt:
             kern[name] = {"launches_per_step": cnt / 2.0, "avg_ms": ms / cnt, "timed_region": False}
     _lib.profile_enable(False)
-    rows_per_sample, ncols = 6, 84
-    bytes_per_sample = 8 * 18 + 8 * rows_per_sample * ncols                      # 4176 B
-    flops_per_sample = 2 * rows_per_sample * (n_kept + 1) ** 2                   # 2 m n^2
+    m = robot.model
+    rows_per_sample = m.nv if param["is_joint_torques"] else 6
+    ncols = len(meta["names_std"])
+    bytes_per_sample = 8 * (m.nq + 2 * m.nv) + 8 * rows_per_sample * ncols        # SURVEY 8(d), stage A
+    flops_per_sample = 2 * rows_per_sample * (n_kept + 1) ** 2                    # SURVEY 8(d), stage B: 2 m n^2
+    launches_per_step = {k: v["launches"] / float(args.steps) for k, v in kern.items() if "launches" in v}
     roof = {}
-    if "regressor_chain" in kern:
-        sec = kern["regressor_chain"]["avg_ms"] * 1e-3
-        roof["regressor_chain"] = {"bound": "hbm", "achieved": bytes_per_sample * N / sec / 1e9, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "traffic": None}
+    if k1_name in kern:
+        sec = kern[k1_name]["avg_ms"] * 1e-3 * launches_per_step[k1_name]  # (the streamed pass runs K1' twice per chunk)
+        roof[k1_name] = {"bound": "hbm", "achieved": bytes_per_sample * N / sec / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_sample": bytes_per_sample}
     if "tsqr" in kern:
-        sec = kern["tsqr"]["avg_ms"] * 1e-3
-        roof["tsqr"] = {"bound": "mfma", "achieved": flops_per_sample * N / sec / 1e12, "peak": FP64_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "traffic": None}
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 as the
-    # gfx950 correction + WRITE_SIZE, tools/pmc_summary.py); PMC cannot be read from inside the process
+        sec = kern["tsqr"]["avg_ms"] * 1e-3 * launches_per_step["tsqr"]
+        roof["tsqr"] = {"bound": "fp64", "achieved": flops_per_sample * N / sec / 1e12, "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "traffic": None, "algorithmic_flops_per_sample": flops_per_sample}
+        if n_kept + 1 <= 80:
+            roof["tsqr"]["pipe"] = ("fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand, no MFMA instruction is issued): "
+                                    "v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak and shares the FP64 datapath "
+                                    "(tools/microbench/latency.hip), so that peak is the roof of this kernel")
+            # the kernel skips the structurally zero leading columns of each joint's row block (structure hint): the
+            # flops it executes are 2 (nc - first_j)^2 per row of block j, not the dense 2 nc^2
+            kept = np.array([meta["names_std"].index(p) for p in out["params_r"]])
+            first = np.searchsorted(kept, 14 * np.arange(rows_per_sample))
+            roof["tsqr"]["executed_flops_per_sample"] = int(sum(2 * (n_kept + 1 - f) ** 2 for f in first))
+        else:
+            roof["tsqr"]["pipe"] = ("fp64 matrix pipe: 16-column panels on the VALU, compact-WY trailing updates as "
+                                    "v_mfma_f64_16x16x4 (figh_tsqr_wide.hip); rows whose leading columns are zero start "
+                                    "at their first non-zero column, so the executed flops are below the dense 2 m n^2")
+    # HBM bytes per launch: PMC counters cannot be read from inside the process -- the number below comes from the
+    # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
+    # tools/pmc_summary.py), i.e. from the builder's run, not from this one
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
             pmc = json.load(f)
-        if N == 1_000_000:
+        if args.config == "cfg2" and N == 1_000_000:
             for key, kname in (("regressor_chain", "regressor_chain_kernel<6, false, true>"),
-                               ("tsqr", "tsqr2_kernel<4, 4, false, false, true>")):
+                               ("tsqr", "tsqr2_kernel<4, 4, true>")):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
-                    roof[key]["traffic_source"] = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                    roof[key]["traffic_source"] = ("profiles/r02_pmc_summary.json: a committed rocprofv3 --pmc run of this "
+                                                   "command, NOT measured in this run")
     except Exception:
         pass
-    if "tsqr" in roof:
-        roof["tsqr"]["pipe"] = ("fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand + permlane swaps); v_mfma_f64_16x16x4 has the "
-                              "same 78.6 TFLOP/s peak and does not overlap with fp64 VALU work (tools/microbench/latency.hip)")
-        roof["tsqr"]["algorithmic_flops_per_sample"] = flops_per_sample
-    if "regressor_chain" in roof:
-        roof["regressor_chain"]["algorithmic_bytes_per_sample"] = bytes_per_sample
     for r in roof.values():
         r["frac"] = r["achieved"] / r["peak"]
-    main = {k: v for k, v in kern.items() if "launches" in v}
-    dominant = max(main, key=lambda k: main[k]["avg_ms"] * main[k]["launches"]) if main else None
+    main_k = {k: v for k, v in kern.items() if "launches" in v}
+    dominant = max(main_k, key=lambda k: main_k[k]["avg_ms"] * main_k[k]["launches"]) if main_k else None
     if rank == 0:
         line = {
-            "metric": "samples/sec regressor build + TSQR solve, UR10 6-DoF",
-            "value": N * world * args.steps / dt,
+            "metric": "samples/sec regressor build + TSQR solve, UR10 6-DoF" if args.config == "cfg2" else
+                      "samples/sec regressor build + TSQR solve, %s" % model_name,
+            "value": n_total * args.steps / dt,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: UR10 6-DoF, %d synthetic (q,qd,qdd) samples per GPU, full inertial "
+                "workload": {
+                    "cfg2": "BASELINE configs[1]: UR10 6-DoF, %d synthetic (q,qd,qdd) samples per GPU, full inertial "
                             "regressor materialised (6N x 84) + elimination + Householder TSQR base params + LS" % N,
-                "samples_per_gpu": N, "columns": ncols, "kept_columns": n_kept, "base_parameters": len(out["idx_base"]),
-                "collective": xinfo["collective"], "device": _lib.device_info()["name"],
-                "result_matches_reference": bool(ok),
+                    "cfg3": "BASELINE configs[2]: TIAGo, fv/fs + actuator inertia + offset columns, %d samples in total, "
+                            "regressor (24N x 336, device-resident, link-padded) + elimination + blocked TSQR + LS" % n_total,
+                    "cfg4": "BASELINE configs[3]: TALOS floating base, external-wrench regressor, %d samples in total "
+                            "sharded over the GPUs, regressor (6N x 462, device-resident, link-padded) + blocked TSQR" % n_total,
+                    "cfg5": "BASELINE configs[4]: human whole-body, %d samples in total sharded over the GPUs, streamed in "
+                            "chunks of %s samples (W = 269 GB never exists in full)" % (n_total, chunk),
+                }[args.config],
+                "samples_this_rank": N, "samples_total": n_total, "columns": ncols, "kept_columns": n_kept,
+                "base_parameters": len(out["idx_base"]), "collective": xinfo["collective"], "ranks": world,
+                "rank0_seconds": dt_rank, "max_rank_seconds": dt,
+                "device": _lib.device_info()["name"], "result_matches_reference": bool(ok),
+                "figh_env": "none set (checked)",
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
             "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline(robot.model.to_flat(), 7, args.cpu_samples)
             line["cpu_baseline_fast"] = cpu_baseline_fast(robot.model.to_flat(), 7, args.cpu_samples)
         print(json.dumps(line))
@@ -223,6 +284,9 @@ def main():
         barrier()
         if hasattr(exchange, "close"):
             exchange.close()
+    if not ok:
+        raise SystemExit("bench.py: the step did not reproduce the reference's structural result (idx_e / idx_base / "
+                         "expressions) -- the line above is not a valid measurement")
 
 
 def meta_idx(meta):

@@ -6,6 +6,7 @@ estimates to 1e-6 relative (BASELINE.json north_star) or to the reference's own 
 """
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -612,3 +613,43 @@ def test_regressor_all_flag_combinations(lib, golden, oracle_lib, flags):
         assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
         ext = [c for c in range(ref.shape[1] - (3 if g.coupling else 0)) if c % 14 >= 10]  # Ia fv fs off slots
         assert np.array_equal(W[:, ext], ref[:, ext])  # copies of v, a, sign(v), 1 and zeros: exact
+
+
+# ------------------------------------------------------------------------------------------------ two ranks, one GPU
+@pytest.mark.timeout(600)
+def test_two_process_pipeline_on_one_device(lib, golden_ur10, tmp_path):
+    """The N > 1 path of the HIP pipeline on the one GPU a test box has: two FRESH processes (subprocess: nothing that
+    has touched the GPU is re-executed), each running IdentificationPipeline on half of the samples with the exchange
+    that dist.exchange_from_env negotiates.  Both ranks name the same device, so the collective preflight must rule RCCL
+    out on every rank (no rank may be left in ncclCommInitRank) and fall back to the host-staged exchange; column norms
+    are all-reduced, the per-rank triangles all-gathered and merged on the device.  Every rank must reproduce the
+    reference's idx_e / idx_base / expressions and phi."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = golden_ur10
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"),
+                                       str(tmp_path / ("rank%d.json" % rank))], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=500)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    for r in res:
+        assert "host-staged" in r["collective"] and "share a device" in r["collective"], r["collective"]
+        assert r["idx_e"] == list(g["idx_e"])
+        assert r["idx_base"] == list(g["idx_base"])
+        assert r["params_base"] == g.meta["params_base"]
+        assert r["rows"] == 6 * len(g["q_big"])
+        phi = np.array(r["phi_ls"])
+        assert np.abs(phi - g["phi_pinv"]).max() <= 1e-6 * np.abs(g["phi_pinv"]).max()
+        assert np.abs(np.array(r["col_norm"]) - g["colsq_big"]).max() <= 1e-12 * g["colsq_big"].max()
+    assert res[0]["phi_ls"] == res[1]["phi_ls"]  # every rank reduces the same stack: bit-identical results

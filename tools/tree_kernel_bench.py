@@ -8,7 +8,7 @@ from figaroh_plus_amd import _lib
 from figaroh_plus_amd.device import GpuMatrix
 from figaroh_plus_amd.tools.regressor import regressor_flags
 from figaroh_plus_amd.tools.robot import Robot
-from gen_golden_inputs import sample_inputs  # noqa
+from figaroh_plus_amd.tools.randomdata import sample_inputs  # noqa
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
 for cfg, mn, N in (("cfg3_tiago", "tiago", 1_000_000), ("cfg4_talos", "talos", 4_000_000), ("cfg5_human", "human", 2_000_000)):
