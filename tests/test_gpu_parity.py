@@ -318,6 +318,114 @@ def test_full_size_structural_invariants(lib, cfg, N, oracle_lib):
     assert np.abs(host_rows - Wsel).max() <= 1e-12 * np.abs(Wsel).max()
 
 
+def _tree_pipeline(cfg, N, seed, chunk=None, tau=True):
+    from conftest import Golden
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
+    g = Golden(cfg)
+    robot = g.robot()
+    q, v, a = sample_inputs(robot.model, N, np.random.default_rng(seed), 1.5, 2, 5)
+    pipe = IdentificationPipeline(robot, g.param, params_std=g.params_std(), coupling=g.coupling, chunk_samples=chunk)
+    pipe.set_samples(q, v, a)
+    if tau:
+        pipe.set_tau_from_parameters(g.phi_ref())
+    return g, pipe, (q, v, a)
+
+
+def _spot_rows_padded(pipe, g, oracle_lib, qva, rps, rng):
+    """Scattered samples of the HBM-resident, LINK-PADDED W (16 columns per link) against the oracle: the 14 reference
+    columns of every link agree, the two padding columns are exactly zero."""
+    from figaroh_plus_amd import _lib
+    q, v, a = qva
+    N = len(q)
+    sel = np.unique(np.concatenate([rng.choice(N, 61, replace=False), [0, 63, 64, N - 65, N - 64, N - 1]]))
+    Wsel = _oracle_W(g, oracle_lib, q[sel], v[sel], a[sel])
+    W = pipe.W
+    assert W.ld % 16 == 0 and W.cols == 16 * (g.robot().model.njoints - 1)
+    rows = np.concatenate([j * N + sel for j in range(rps)])
+    host = np.empty((len(rows), W.ld))
+    for k, r in enumerate(rows):
+        _lib.check(_lib.load().figh_memcpy_d2h(host[k].ctypes.data, W.buf.ptr + int(r) * W.ld * 8, W.ld * 8))
+    nl = W.cols // 16
+    ref_cols = (np.arange(14 * nl) // 14) * 16 + np.arange(14 * nl) % 14
+    assert np.abs(host[:, ref_cols] - Wsel).max() <= 1e-12 * np.abs(Wsel).max()
+    pad = np.setdiff1d(np.arange(W.cols), ref_cols)
+    assert not host[:, pad].any()
+
+
+@pytest.mark.timeout(900)
+def test_full_size_tiago_and_rank_crossing(lib, oracle_lib):
+    """BASELINE configs[2] (TIAGo, fv/fs/Ia/off, 1e6 samples = 24e6 x 336) at full size, plus the finding that comes with
+    it: four structurally dependent pivots of the TIAGo regressor are genuine tiny numbers that grow like sqrt(N)
+    (6.3e-9 at 1e5 samples, 1.26e-8 at 4e5) and cross TOL_QR = 1e-8, so the base-parameter count goes 179 -> 183 -> 185
+    with N -- in the REFERENCE too (np.linalg.qr of the same rows).  Checked here against LAPACK at 1e5 samples (all
+    pivots, identical index set = the golden 179), through the sqrt(N) law at 4e5, and structurally at 1e6."""
+    rng = np.random.default_rng(11)
+    # (i) 1e5 samples: every |R_ii| against LAPACK on the same matrix, base set = golden
+    g, pipe, qva = _tree_pipeline("cfg3_tiago", 100_000, 5)
+    out1 = pipe.run()
+    assert out1["idx_e"] == list(g["idx_e"]) and out1["idx_base"] == list(g["idx_base"])
+    assert out1["params_base"] == g.meta["params_base"]
+    W_ref = _oracle_W(g, oracle_lib, *qva)
+    keep = [i for i in range(W_ref.shape[1]) if i not in set(out1["idx_e"])]
+    d_ref = np.abs(np.diag(np.linalg.qr(W_ref[:, keep], mode="r")))
+    del W_ref
+    big = d_ref > 1e-8
+    # (raw pivots of an UNPIVOTED QR are only comparable up to the direction of the noise reflectors of the dependent
+    # columns in front of them -- SURVEY.md section 7 -- so: the decision exactly, the magnitudes loosely, and the four
+    # borderline pivots, which carry the finding, tightly)
+    assert [i for i in range(len(keep)) if big[i]] == out1["idx_base"]
+    assert np.abs(out1["absdiagR"][big] / d_ref[big] - 1.0).max() <= 1e-3
+    dep1 = np.sort(out1["absdiagR"][~big])[-4:]  # the four borderline pivots
+    assert np.abs(np.sort(d_ref[~big])[-4:] / dep1 - 1.0).max() <= 1e-4 and dep1.min() > 3e-9
+    del pipe
+    # (ii) 4e5 samples: the same four pivots have doubled (sqrt(4)) and crossed the tolerance
+    g, pipe, _ = _tree_pipeline("cfg3_tiago", 400_000, 5)
+    out4 = pipe.run()
+    assert out4["idx_e"] == list(g["idx_e"]) and len(out4["idx_base"]) == 183
+    crossed = sorted(set(out4["idx_base"]) - set(out1["idx_base"]))
+    assert len(crossed) == 4 and set(out1["idx_base"]) <= set(out4["idx_base"])
+    ratio = np.sort(out4["absdiagR"][crossed]) / np.sort(dep1)
+    assert np.all((ratio > 1.7) & (ratio < 2.3)), ratio
+    del pipe
+    # (iii) the BASELINE size
+    g, pipe, qva = _tree_pipeline("cfg3_tiago", 1_000_000, 5)
+    out = pipe.run()
+    assert out["idx_e"] == list(g["idx_e"]) and out["rows"] == 24_000_000
+    assert set(out4["idx_base"]) <= set(out["idx_base"]) and len(out["idx_base"]) in (183, 184, 185)
+    kept = np.array([i for i in range(336) if i not in set(out["idx_e"])])
+    assert np.abs(out["absdiagR"][0] ** 2 - out["col_norm"][kept[0]]) <= 1e-10 * out["col_norm"][kept[0]]  # R_00^2 = ||w_0||^2
+    _spot_rows_padded(pipe, g, oracle_lib, qva, 24, rng)
+
+
+@pytest.mark.timeout(900)
+def test_full_size_talos(lib, oracle_lib):
+    """BASELINE configs[3] (TALOS floating base, external wrench, 4e6 samples = 24e6 x 462) on one GPU: the structural
+    results are the golden ones (produced by the reference's code at 32 / 400 samples), phi reproduces the regrouped
+    standard parameters, and the triangle satisfies R^T R = W^T W on its diagonal (column norms from the fused K1' pass)."""
+    rng = np.random.default_rng(12)
+    g, pipe, qva = _tree_pipeline("cfg4_talos", 4_000_000, 5)
+    out = pipe.run()
+    assert out["idx_e"] == list(g["idx_e"]) and out["rows"] == 24_000_000
+    assert out["idx_base"] == list(g["idx_base"]) and out["params_base"] == g.meta["params_base"]
+    assert np.abs(out["phi_ls"] - g["phi_from_std"]).max() <= 1e-6 * np.abs(g["phi_from_std"]).max()
+    dep = np.setdiff1d(np.arange(len(out["params_r"])), out["idx_base"])
+    assert out["absdiagR"][dep].max() < 1e-8 < out["absdiagR"][out["idx_base"]].min()
+    _spot_rows_padded(pipe, g, oracle_lib, qva, 6, rng)
+
+
+@pytest.mark.timeout(900)
+def test_full_size_human_streamed(lib):
+    """BASELINE configs[4] (human whole body) streamed, at 2e6 of its 1e7 samples (12e6 x 560 = 54 GB of W that never
+    exists in full: chunks of 250 000 samples, norms-only first pass, link-padded chunk workspace): golden idx_e,
+    idx_base and expressions, phi to 1e-6."""
+    g, pipe, _ = _tree_pipeline("cfg5_human", 2_000_000, 5, chunk=250_000)
+    out = pipe.run()
+    assert out["idx_e"] == list(g["idx_e"]) and out["rows"] == 12_000_000
+    assert out["idx_base"] == list(g["idx_base"]) and out["params_base"] == g.meta["params_base"]
+    assert np.abs(out["phi_ls"] - g["phi_from_std"]).max() <= 1e-6 * np.abs(g["phi_from_std"]).max()
+
+
 # ------------------------------------------------------------------------------------------------ RCCL plumbing
 def test_rccl_single_rank_roundtrip(lib):
     """The RCCL entry points on the one GPU a test box has: communicator of size 1, all-gather and all-reduce
