@@ -171,10 +171,44 @@ def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks):
 
 
 # ----------------------------------------------------------------------------------------------------------
-# Pre-processing on either side of the hot path ("next" row).  Host NumPy / SciPy for now:
-# O(N nq) work on the trajectories, same statements and quirks as the reference.
+# Pre-processing on either side of the hot path ("next" row): finite differences and row
+# rejection are O(N nq) NumPy statements as in the reference; the filters run on the device (figh_filtfilt_cols below).
+def _quat_to_rot(x, y, z, w):
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _log3(R):
+    tr = min(1.0, max(-1.0, (np.trace(R) - 1.0) / 2.0))
+    theta = np.arccos(tr)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if theta < 1e-8:
+        return 0.5 * w
+    if np.pi - theta < 1e-6:
+        A = (R + np.eye(3)) / 2.0
+        k = int(np.argmax(np.diag(A)))
+        ax = A[:, k] / np.sqrt(A[k, k])
+        return theta * (ax if w @ ax >= 0 else -ax)
+    return theta / (2.0 * np.sin(theta)) * w
+
+
+def _log6(R, p):
+    """SE(3) logarithm, (linear, angular): w = log3(R), v = alpha p - w x p / 2 + beta (w . p) w."""
+    w = _log3(R)
+    t = np.linalg.norm(w)
+    if t < 1e-4:
+        alpha, beta = 1.0 - t * t / 12.0 - t ** 4 / 720.0, 1.0 / 12.0 + t * t / 720.0
+    else:
+        st, ct = np.sin(t), np.cos(t)
+        alpha, beta = t * st / (2.0 * (1.0 - ct)), 1.0 / (t * t) - st / (2.0 * t * (1.0 - ct))
+    return alpha * p - 0.5 * np.cross(w, p) + beta * (w @ p) * w, w
+
+
 def joint_difference(model, q0, q1):
-    """``pin.difference(model, q0, q1)`` for the joint types of the URDF loader (tangent-space difference)."""
+    """``pin.difference(model, q0, q1)`` (identification_tools.py:370,376) for the joint types of the URDF loader: the
+    tangent vector from q0 to q1 -- q1 - q0 for revolute / prismatic joints, the angle of R0^T R1 for continuous ones
+    (cos, sin), log6(M0^-1 M1) in the local frame for a free-flyer (linear, angular)."""
     out = np.zeros(model.nv)
     for j in model.joints[1:]:
         if j.jtype in (0, 1):
@@ -182,8 +216,11 @@ def joint_difference(model, q0, q1):
         elif j.jtype == 2:  # (cos, sin): angle of R0^T R1
             c0, s0, c1, s1 = q0[j.idx_q], q0[j.idx_q + 1], q1[j.idx_q], q1[j.idx_q + 1]
             out[j.idx_v] = np.arctan2(s1 * c0 - c1 * s0, c1 * c0 + s1 * s0)
-        else:
-            raise NotImplementedError("joint_difference: free-flyer joints (SE(3) log) are not implemented yet")
+        else:  # free-flyer: q = [p, qx qy qz qw]
+            iq, iv = j.idx_q, j.idx_v
+            R0, R1 = _quat_to_rot(*q0[iq + 3:iq + 7]), _quat_to_rot(*q1[iq + 3:iq + 7])
+            v, w = _log6(R0.T @ R1, R0.T @ (np.asarray(q1[iq:iq + 3]) - np.asarray(q0[iq:iq + 3])))
+            out[iv:iv + 3], out[iv + 3:iv + 6] = v, w
     return out
 
 

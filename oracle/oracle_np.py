@@ -424,3 +424,84 @@ def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
         W_list.append(np.ascontiguousarray(blk))
         tau_list.append(t)
     return W_list, tau_list
+
+
+# ------------------------------------------------------------------------------------------- pin.difference (restated)
+def quat_to_rot(qx, qy, qz, qw):
+    x, y, z, w = qx, qy, qz, qw
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def log3(R):
+    """Rotation vector of R (Pinocchio log3): angle from the trace, axis from the antisymmetric part."""
+    tr = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    theta = np.arccos(tr)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if theta < 1e-8:
+        return 0.5 * w
+    if np.pi - theta < 1e-6:  # near pi: axis from the symmetric part
+        A = (R + np.eye(3)) / 2.0
+        k = int(np.argmax(np.diag(A)))
+        ax = A[:, k] / np.sqrt(A[k, k])
+        if w @ ax < 0:
+            ax = -ax
+        return theta * ax
+    return theta / (2.0 * np.sin(theta)) * w
+
+
+def log6(R, p):
+    """Twist (v, w) with exp6(v, w) = (R, p) -- Pinocchio log6 (Spatial/explog.hpp): w = log3(R),
+    v = alpha p - w x p / 2 + beta (w . p) w."""
+    w = log3(R)
+    t = np.linalg.norm(w)
+    if t < 1e-4:
+        alpha = 1.0 - t * t / 12.0 - t ** 4 / 720.0
+        beta = 1.0 / 12.0 + t * t / 720.0
+    else:
+        st, ct = np.sin(t), np.cos(t)
+        alpha = t * st / (2.0 * (1.0 - ct))
+        beta = 1.0 / (t * t) - st / (2.0 * t * (1.0 - ct))
+    v = alpha * p - 0.5 * np.cross(w, p) + beta * (w @ p) * w
+    return v, w
+
+
+def joint_difference(flat, q0, q1):
+    """pin.difference(model, q0, q1) (call sites: identification_tools.py:370,376): the tangent vector that takes q0 to
+    q1.  Revolute / prismatic: q1 - q0; continuous (cos, sin): the angle of R0^T R1; free-flyer: log6(M0^-1 M1) in the
+    local frame of M0, ordered (linear, angular)."""
+    out = np.zeros(int(flat["nv"]))
+    for j in range(1, int(flat["njoints"])):
+        jt, iq, iv = int(flat["jtype"][j]), int(flat["idx_q"][j]), int(flat["idx_v"][j])
+        if jt in (0, 1):
+            out[iv] = q1[iq] - q0[iq]
+        elif jt == 2:
+            c0, s0, c1, s1 = q0[iq], q0[iq + 1], q1[iq], q1[iq + 1]
+            out[iv] = np.arctan2(s1 * c0 - c1 * s0, c1 * c0 + s1 * s0)
+        else:
+            R0, R1 = quat_to_rot(*q0[iq + 3:iq + 7]), quat_to_rot(*q1[iq + 3:iq + 7])
+            v, w = log6(R0.T @ R1, R0.T @ (q1[iq:iq + 3] - q0[iq:iq + 3]))
+            out[iv:iv + 3], out[iv + 3:iv + 6] = v, w
+    return out
+
+
+def qr_pivoting(tau, W_e, params_r, tol_qr=1e-8):
+    """src/figaroh/tools/qrdecomposition.py:24-86 restated: column-pivoted QR, rank = index of the first pivot that is
+    NOT above tol_qr (so a full-rank W_e gives rank 0: the loop never reaches its else branch), beta and phi_b rounded to
+    6 decimals, expressions as in get_baseParams.  Returns (W_b, {expression: phi})."""
+    from scipy import linalg
+    Q, R, P = linalg.qr(W_e, pivoting=True, mode="economic")
+    sorted_names = [params_r[P[i]] for i in range(P.shape[0])]
+    rank = 0
+    d = np.diag(R)
+    for i in range(d.shape[0]):
+        if abs(d[i]) > tol_qr:
+            continue
+        rank = i
+        break
+    R1, Q1, R2 = R[:rank, :rank], Q[:, :rank], R[:rank, rank:]
+    beta = np.around(np.linalg.inv(R1) @ R2, 6)
+    phi_b = np.round(np.linalg.inv(R1) @ (Q1.T @ tau), 6)
+    names = regroup_strings(sorted_names[:rank], sorted_names[rank:], beta)
+    return Q1 @ R1, dict(zip(names, phi_b))

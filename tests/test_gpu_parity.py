@@ -426,6 +426,31 @@ def test_full_size_human_streamed(lib):
     assert np.abs(out["phi_ls"] - g["phi_from_std"]).max() <= 1e-6 * np.abs(g["phi_from_std"]).max()
 
 
+def test_qr_pivoting_matches_reference(lib, golden):
+    """QR_pivoting (qrdecomposition.py:24-86) through the TSQR triangle against the output of the reference's own
+    function: same expressions in the same (pivoted) order, phi to the reference's 6-decimal rounding, W_b = the pivoted
+    base columns, and the rank-0 result for a full-rank input (the reference's loop never reaches its else branch)."""
+    import json
+    from conftest import GOLD
+    from figaroh_plus_amd.tools.qrdecomposition import QR_pivoting
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic, build_regressor_reduced
+    with open(os.path.join(GOLD, "qr_pivoting.json")) as f:
+        gq = json.load(f)
+    if golden.name not in gq:
+        pytest.skip("no QR_pivoting fixture for this config")
+    ref = gq[golden.name]
+    g = golden
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    W_e = build_regressor_reduced(W, list(g["idx_e"]))
+    W_b, bp = QR_pivoting(g["tau"], W_e, g.meta["params_r"])
+    assert list(bp.keys()) == ref["expressions"]
+    assert np.abs(np.array(list(bp.values())) - np.array(ref["phi_b"])).max() <= 1.5e-6
+    assert list(W_b.shape) == ref["W_b_shape"]
+    assert abs(np.abs(W_b).sum() - ref["W_b_checksum"][1]) <= 1e-9 * ref["W_b_checksum"][1]
+    W_b0, bp0 = QR_pivoting(g["tau"], W_e[:, g["idx_base"]], [g.meta["params_r"][i] for i in g["idx_base"]])
+    assert list(W_b0.shape) == ref["full_rank_result"]["W_b_shape"] and len(bp0) == 0
+
+
 # ------------------------------------------------------------------------------------------------ RCCL plumbing
 def test_rccl_single_rank_roundtrip(lib):
     """The RCCL entry points on the one GPU a test box has: communicator of size 1, all-gather and all-reduce

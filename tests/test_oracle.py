@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 import oracle_np
 from conftest import GOLD
@@ -142,3 +143,45 @@ def test_tx40_real_data_known_answers(oracle_lib):
     phi_w, std_w = oracle_np.wls_script(res["W_b"], tau_, res["phi_b"], counts)
     assert np.abs(phi_w - z["phi_wls"]).max() <= 2e-6
     assert np.abs(phi_w - csvv[:, 2]).max() <= 4e-4                # committed phi_WLS
+
+
+def test_se3_log_matches_matrix_logarithm():
+    """oracle_np.log6 (the restated pin.difference of a free-flyer) against an independent reference: the twist read off
+    scipy.linalg.logm of the 4 x 4 homogeneous matrix.  Small, generic and near-pi rotation angles."""
+    from scipy.linalg import logm
+    rng = np.random.default_rng(5)
+    for angle in (1e-9, 1e-5, 0.3, 1.7, 3.0, np.pi - 1e-7):
+        ax = rng.standard_normal(3)
+        ax /= np.linalg.norm(ax)
+        K = oracle_np.skew(ax)
+        R = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K
+        p = rng.uniform(-2, 2, 3)
+        v, w = oracle_np.log6(R, p)
+        M = np.eye(4)
+        M[:3, :3], M[:3, 3] = R, p
+        L = np.real(logm(M))
+        w_ref = np.array([L[2, 1], L[0, 2], L[1, 0]])
+        tol = 1e-6 if np.pi - angle < 1e-3 else 1e-9  # logm itself loses digits next to pi
+        assert np.abs(w - w_ref).max() <= tol and np.abs(v - L[:3, 3]).max() <= tol
+
+
+def test_numpy_oracle_reproduces_reference_qr_pivoting(golden):
+    """QR_pivoting (qrdecomposition.py:24-86): the restatement against the output of the reference's own function
+    (oracle/gen_golden_extra.py), including the rank-0 result for a full-rank input."""
+    import json
+    with open(os.path.join(GOLD, "qr_pivoting.json")) as f:
+        gq = json.load(f)
+    if golden.name not in gq:
+        pytest.skip("no QR_pivoting fixture for this config")
+    ref = gq[golden.name]
+    W = oracle_np.build_regressor_basic(golden.flat(), golden["q_big"], golden["v_big"], golden["a_big"], golden.param)
+    if golden.coupling:
+        W = oracle_np.add_coupling_TX40(W, len(golden["q_big"]), golden["v_big"], golden["a_big"])
+    keep = [i for i in range(W.shape[1]) if i not in set(golden["idx_e"].tolist())]
+    W_b, bp = oracle_np.qr_pivoting(golden["tau"], W[:, keep], golden.meta["params_r"])
+    assert list(bp.keys()) == ref["expressions"]
+    assert np.abs(np.array(list(bp.values())) - np.array(ref["phi_b"])).max() <= 1e-6
+    assert list(W_b.shape) == ref["W_b_shape"]
+    W_b0, bp0 = oracle_np.qr_pivoting(golden["tau"], W[:, keep][:, golden["idx_base"]],
+                                      [golden.meta["params_r"][i] for i in golden["idx_base"]])
+    assert list(W_b0.shape) == ref["full_rank_result"]["W_b_shape"] and len(bp0) == 0
