@@ -235,6 +235,20 @@ def main():
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
                     roof[key]["traffic_source"] = ("profiles/r02_pmc_summary.json: a committed rocprofv3 --pmc run of this "
                                                    "command, NOT measured in this run")
+        if args.config == "cfg4" and N == 4_000_000:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_summary_cfg4.json")) as f:
+                pmc = json.load(f)
+            src = "profiles/r02_pmc_summary_cfg4.json: a committed rocprofv3 --pmc run of this command, NOT measured in this run"
+            for key, kname in (("regressor_tree", "regressor_tape_kernel<16, true, true, true, true>"),
+                               ("tsqr", "tsqr_wy_kernel<4, 6, 3, 2>")):
+                if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
+                    roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
+                    roof[key]["traffic_source"] = src
+            k = pmc.get("tsqr_wy_kernel<4, 6, 3, 2>", {})
+            if "tsqr" in roof and "SQ_INSTS_VALU_MFMA_MOPS_F64" in k:
+                # one MOPS unit = 512 flops (4 units per v_mfma_f64_16x16x4 = 2048 flops, checked against SQ_INSTS_MFMA)
+                roof["tsqr"]["executed_mfma_flops_per_launch"] = 512.0 * k["SQ_INSTS_VALU_MFMA_MOPS_F64"]
+                roof["tsqr"]["mfma_counters_source"] = src
     except Exception:
         pass
     for r in roof.values():

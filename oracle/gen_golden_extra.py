@@ -44,6 +44,11 @@ def qr_pivoting_fixture():
         W_b0, base0 = gg.ref_qr.QR_pivoting(tau, W_full, list(names_full))
         out[cfg] = {"expressions": list(base_parameters.keys()), "phi_b": [float(x) for x in base_parameters.values()],
                     "W_b_shape": list(W_b.shape), "W_b_checksum": [float(W_b.sum()), float(np.abs(W_b).sum())],
+                    # tie-break independent invariants (the pivot order among equal trailing norms is roundoff noise:
+                    # LAPACK on W_e perturbed by 1e-15 relative already changes P): the fitted torques and the residual
+                    "prediction_norm": float(np.linalg.norm(W_b @ np.array(list(base_parameters.values())))),
+                    "residual_norm": float(np.linalg.norm(tau - W_b @ np.array(list(base_parameters.values())))),
+                    "W_b_colnorm_max": float(np.linalg.norm(W_b, axis=0).max()),
                     "full_rank_result": {"W_b_shape": list(W_b0.shape), "n_parameters": len(base0)}}
         print(cfg, "QR_pivoting:", len(base_parameters), "parameters; full-rank input ->", W_b0.shape, len(base0))
     with open(os.path.join(GOLD, "qr_pivoting.json"), "w") as f:

@@ -10,6 +10,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     return re.sub(r"\(.*$", "", name).replace("void figh::", "").replace("figh::", "")
 
 
