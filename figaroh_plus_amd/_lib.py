@@ -52,6 +52,7 @@ SIGNATURES = {
     "figh_coupling_tx40": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "figh_colsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p]),
     "figh_gather_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "figh_place_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_int64]),
     "figh_matvec": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "figh_block_sqnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "figh_tsqr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int,
@@ -263,6 +264,11 @@ def colsq(d_W, rows, cols, ldw, d_out):
 
 def gather_cols(d_W, rows, ldw, d_idx, n, d_out, ldo):
     check(load().figh_gather_cols(d_W.ptr, rows, ldw, d_idx.ptr, n, d_out.ptr, ldo))
+
+
+def place_block(src_ptr, ld_src, rows, cols, scale, dst_ptr, ld_dst):
+    """Raw device addresses (``DeviceArray.ptr`` + a byte offset): the blocks are sub-matrices."""
+    check(load().figh_place_block(src_ptr, ld_src, rows, cols, scale, dst_ptr, ld_dst))
 
 
 def matvec(d_W, rows, ldw, d_idx, n, d_x, d_y):

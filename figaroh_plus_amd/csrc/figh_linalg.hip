@@ -482,6 +482,19 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const double *__restri
     }
 }
 
+// dst[r][c] = scale * src[r][c] for a rows x cols block (strided 2-D copy): the np.concatenate / negation statements
+// that assemble the total-least-squares regressor (regressor.py:316-412, :446-490).  A thread handles one element;
+// consecutive threads run along a row.
+__global__ __launch_bounds__(256) void place_block_kernel(const double *__restrict__ src, long lds, long rows, long cols,
+                                                          double scale, double *__restrict__ dst, long ldd) {
+    const long total = rows * cols;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / cols;
+        const long c = e - r * cols;
+        dst[r * ldd + c] = scale * src[r * lds + c];
+    }
+}
+
 // qrdecomposition.py:215-236: idx_base = {i : |R_ii| > tol}, then the regrouped column order [base | rest | tau].
 // One wave, stable partition by ballot prefix counts; n <= 512.
 __global__ __launch_bounds__(64) void base_permutation_kernel(const double *__restrict__ R, const int nc, const int n,
@@ -700,6 +713,21 @@ int figh_gather_cols(const double *d_W, int64_t rows, int64_t ldw, const int32_t
     ProfileScope scope("gather_cols");
     hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_W, (long)rows, (long)ldw,
                        d_col_idx, n, d_out, (long)ldo);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int figh_place_block(const double *d_src, int64_t ld_src, int64_t rows, int64_t cols, double scale, double *d_dst,
+                     int64_t ld_dst) {
+    FIGH_REQUIRE(d_src && d_dst, "NULL device pointer");
+    FIGH_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    if (rows == 0 || cols == 0) return FIGH_OK;
+    long blocks = (rows * cols + 255) / 256;
+    if (blocks > cu_count() * 16L) blocks = cu_count() * 16L;
+    ProfileScope scope("place_block");
+    hipLaunchKernelGGL(place_block_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_src, (long)ld_src, (long)rows,
+                       (long)cols, scale, d_dst, (long)ld_dst);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }

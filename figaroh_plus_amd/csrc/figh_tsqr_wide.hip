@@ -58,6 +58,10 @@ namespace {
 #define FIGH_PROF_STORE(ptr, w, nw) do {} while (0)
 #endif
 
+#ifdef FIGH_ABLATION
+__device__ int g_wy_ralias = 0;
+#endif
+
 constexpr int kLdv = 17;  // LDS row stride of V (doubles): the transposed reads of B -= V Wm hit 16 different banks
 
 constexpr int kLdt = 17;  // LDS row stride of T (doubles): T[row][col] at row * kLdt + col
@@ -264,7 +268,13 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int nch = (nc + 15) >> 4;
+#ifdef FIGH_ABLATION
+    // FIGH_WY_RALIAS: the workgroups of an XCD share ONE triangle (garbage results, same instruction stream): what the
+    // kernel would cost if the R blocks came from L2 instead of HBM / MALL
+    double *Rb = Rblk + (long)(g_wy_ralias ? (blockIdx.x & 7) : blockIdx.x) * ((long)nch * (nch + 1) / 2) * 256;
+#else
     double *Rb = Rblk + (long)blockIdx.x * ((long)nch * (nch + 1) / 2) * 256;
+#endif
     auto block = [&](const int p, const int cc) { return Rb + ((long)cc * (cc + 1) / 2 + p) * 256; };
     double *Rl = rpp[wave];
     double *red = redbuf[wave];
@@ -631,6 +641,12 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
 #ifdef FIGH_ABLATION
     const WyConfig pcfg = wy_config(nc);
     static const bool want_prof = getenv("FIGH_WY_PROF") != nullptr;
+    static bool alias_set = false;
+    if (!alias_set) {
+        const int v = getenv("FIGH_WY_RALIAS") != nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_wy_ralias), &v, sizeof(int));
+        alias_set = true;
+    }
     if (want_prof && rows >= 65536) {
         prof = static_cast<long long *>(workspace(sizeof(long long) * 12 * nwg * pcfg.nw, 6));
         if (!prof) return FIGH_ERR_ALLOC;

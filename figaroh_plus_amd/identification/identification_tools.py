@@ -354,3 +354,74 @@ def sip_qp_terms(robot, q, v, a, tau, param, col_idx, phi_ref, alpha, coupling=F
     P = (1 - alpha) * sf1 * np.eye(n) + alpha * sf2 * G
     r = -((1 - alpha) * sf1 * phi_ref + sf2 * alpha * g)
     return P, r
+
+
+def quadprog_solve_qp(P, q, G=None, h=None, A=None, b=None):
+    """``minimize 1/2 x^T P x + q^T x  s.t.  G x <= h, A x = b`` -- identification_tools.py:429-463, statement by
+    statement; the Goldfarb-Idnani solve itself is ``qp.solve_qp`` (quadprog is a third-party dependency of the
+    reference)."""
+    from .qp import solve_qp
+
+    qp_G = 0.5 * (P + P.T) + np.eye(P.shape[0]) * (1e-5)  # make sure P is symmetric, pos,def
+    qp_a = -q
+    if A is not None:
+        qp_C = -np.vstack([A, G]).T
+        qp_b = -np.hstack([b, h])
+        meq = A.shape[0]
+    else:  # no equality constraint
+        qp_C = -G.T
+        qp_b = -h
+        meq = 0
+    return solve_qp(qp_G, qp_a, qp_C, qp_b, meq)[0]
+
+
+def sip_constraints(phi_ref, COM_max, COM_min):
+    """G, h of identification_tools.py:533-566: 14 bound rows per massed body -- first moments inside
+    [COM_min, COM_max], mass and Ixx, Iyy, Izz inside [0.7, 1.3] x their reference values."""
+    phi_ref = np.asarray(phi_ref, dtype=np.float64)
+    nreal = phi_ref.shape[0] // 10
+    G = np.zeros((14 * nreal, 10 * nreal))
+    h = np.zeros(14 * nreal)
+    for ii in range(nreal):
+        for k in range(3):  # mx, my, mz
+            G[14 * ii + 2 * k, ii * 10 + 6 + k] = 1
+            h[14 * ii + 2 * k] = COM_max[3 * ii + k]
+            G[14 * ii + 2 * k + 1, ii * 10 + 6 + k] = -1
+            h[14 * ii + 2 * k + 1] = -COM_min[3 * ii + k]
+        for k, col in enumerate((9, 0, 3, 5)):  # m, Ixx, Iyy, Izz
+            G[14 * ii + 6 + 2 * k, ii * 10 + col] = 1
+            h[14 * ii + 6 + 2 * k] = 1.3 * phi_ref[ii * 10 + col]
+            G[14 * ii + 7 + 2 * k, ii * 10 + col] = -1
+            h[14 * ii + 7 + 2 * k] = -0.7 * phi_ref[ii * 10 + col]
+    return G, h
+
+
+def calculate_standard_parameters(model, W, tau, COM_max, COM_min, params_standard_u, alpha):
+    """(phi_standard, phi_ref) -- identification_tools.py:466-572: the standard inertial parameters that fit the
+    measurements (weight alpha), stay near the URDF values (weight 1 - alpha) and keep first moments, masses and
+    principal inertias inside their bounds.  ``W`` (host array or ``GpuMatrix``, 10 columns per massed body) is
+    reduced on the device: ``W^T W`` and ``W^T tau`` are formed from the Householder triangle of ``[W tau]``
+    (``figh_tsqr``); the 10 nreal-variable program is solved on the host."""
+    phi_ref = []
+    id_inertias = [jj for jj in range(len(model.inertias)) if model.inertias[jj].mass != 0]
+    nreal = len(id_inertias)
+    params_name = ("Ixx", "Ixy", "Ixz", "Iyy", "Iyz", "Izz", "mx", "my", "mz", "m")
+    for k in range(nreal):
+        for j in params_name:
+            phi_ref.append(params_standard_u[j + str(id_inertias[k])])
+    phi_ref = np.array(phi_ref)
+    tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(-1)
+    Wd, _ = to_device(W)
+    n = Wd.cols
+    if n != 10 * nreal:
+        raise ValueError("W has %d columns, the model has %d bodies with mass (10 columns each)" % (n, nreal))
+    R = rfactor(Wd, tau=tau)  # [R z; 0 rho]: W^T W = R^T R, W^T tau = R^T z
+    WtW = R[:n, :n].T @ R[:n, :n]
+    Wttau = R[:n, :n].T @ R[:n, n]
+    sf1 = 1 / (np.max(phi_ref) * len(phi_ref))
+    sf2 = 1 / (np.max(tau) * len(tau))
+    P = (1 - alpha) * sf1 * np.eye(n) + alpha * sf2 * WtW
+    r = -((1 - alpha) * sf1 * phi_ref.T + sf2 * alpha * Wttau)
+    G, h = sip_constraints(phi_ref, COM_max, COM_min)
+    phi_standard = quadprog_solve_qp(P, r, G, h)
+    return phi_standard, phi_ref

@@ -133,3 +133,114 @@ def build_regressor_reduced(W, idx_e):
     """``np.delete(W, idx_e, 1)`` on the device (regressor.py:282-293)."""
     Wd, on_dev = to_device(W)
     return _delete_columns(Wd, idx_e, on_dev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Total-least-squares payload regressors (regressor.py:296-500), SURVEY section 8f-4.  W_tot is assembled in HBM block
+# by block (figh_place_block: the concatenate / unary minus / zeros statements), its triangle comes from the TSQR
+# kernel, the n x n SVD (n = columns of W_tot, a few dozen to a few hundred) runs on the host on that triangle -- the
+# right singular vectors and singular values of W_tot are those of R -- and the residue is one device mat-vec.
+def _place(src, r0, c0, rows, cols, scale, dst, dr0, dc0):
+    _lib.place_block(src.ptr + 8 * (r0 * src.ld + c0), src.ld, rows, cols, scale,
+                     dst.ptr + 8 * (dr0 * dst.ld + dc0), dst.ld)
+
+
+def _blockdiag_columns(vec, nblocks, n, dst, r0, c0):
+    """V_a / V_b of regressor.py:321-343 (and tau_ul / tau_l of :448-481): column ii holds entries ii*n .. (ii+1)*n - 1
+    of ``vec`` in the same rows, zeros elsewhere."""
+    d = GpuMatrix(_lib.DeviceArray.from_host(np.ascontiguousarray(vec, dtype=np.float64).reshape(-1)), nblocks * n, 1)
+    for ii in range(nblocks):
+        _place(d, ii * n, 0, n, 1, 1.0, dst, r0 + ii * n, c0 + ii)
+
+
+def _tls_solution(Wt, mass_load):
+    from .qrdecomposition import rfactor
+    R = rfactor(Wt)
+    _, _, Vh = np.linalg.svd(R, full_matrices=False)
+    V = np.transpose(Vh).conj()
+    V_norm = mass_load * np.divide(V[:, -1], V[-1, -1])
+    d_x = _lib.DeviceArray.from_host(np.ascontiguousarray(V_norm))
+    d_y = _lib.DeviceArray((Wt.rows,), np.float64)
+    _lib.matvec(Wt.buf, Wt.rows, Wt.ld, None, Wt.cols, d_x, d_y)
+    return V_norm, d_y.to_host()
+
+
+def _payload_columns(W_l, first, picks, width, param_standard_l, eliminate):
+    """W_l_temp of regressor.py:346-349 / :366-369 / :386-388 / :483-487: ``width`` columns, those in ``picks`` copied
+    from W_l[:, first + k], the others zero; with ``eliminate`` the columns whose squared norm is below 1e-6 are dropped
+    (get_index_eliminate + build_regressor_reduced)."""
+    tmp = GpuMatrix.empty(W_l.rows, width)
+    tmp.buf.zero_()
+    if first + max(picks) >= W_l.cols:
+        raise IndexError("index %d is out of bounds for axis 1 with size %d" % (first + max(picks), W_l.cols))
+    for k in picks:
+        _place(W_l, 0, first + k, W_l.rows, 1, 1.0, tmp, 0, k)
+    if not eliminate:
+        return tmp
+    idx_e, _ = get_index_eliminate(tmp, param_standard_l, 1e-6)
+    return build_regressor_reduced(tmp, idx_e)
+
+
+def _total_regressor(W_b_u, W_b_l, W_l, meas_u, meas_l, nblocks, n_u, n_l, W_e_l, mass_col, param, on_dev):
+    nb = W_b_u.cols
+    if W_b_l.cols != nb:
+        raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
+    total = W_b_u.rows + W_b_l.rows
+    if nblocks * (n_u + n_l) != total or 2 * W_l.rows != total:
+        # np.concatenate((W_tot, W_current), axis=1) / ((W_tot, W_upayload), axis=1) of the reference: the measurement
+        # columns have len(meas_u) + len(meas_l) rows, the payload columns 2 len(W_l)
+        raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
+    rows_u, rows_l = W_b_u.rows, W_b_l.rows
+    ncols = nb + nblocks + W_e_l.cols + 1
+    Wt = GpuMatrix.empty(rows_u + rows_l, ncols)
+    Wt.buf.zero_()
+    _place(W_b_u, 0, 0, rows_u, nb, -1.0, Wt, 0, 0)
+    _place(W_b_l, 0, 0, rows_l, nb, -1.0, Wt, rows_u, 0)
+    _blockdiag_columns(meas_u, nblocks, n_u, Wt, 0, nb)
+    _blockdiag_columns(meas_l, nblocks, n_l, Wt, nblocks * n_u, nb)  # below the unloaded measurements
+    _place(W_e_l, 0, 0, W_l.rows, W_e_l.cols, -1.0, Wt, W_l.rows, nb + nblocks)  # below len(W_l) zero rows
+    _place(W_l, 0, mass_col, W_l.rows, 1, -1.0, Wt, W_l.rows, nb + nblocks + W_e_l.cols)
+    V_norm, residue = _tls_solution(Wt, param["mass_load"])
+    return (Wt if on_dev else Wt.numpy()), V_norm, residue
+
+
+def build_total_regressor_current(W_b_u, W_b_l, W_l, I_u, I_l, param_standard_l, param):
+    """(W_tot, V_norm, residue) -- regressor.py:296-412: unloaded and loaded base regressors stacked, the joint currents
+    as block-diagonal columns (one drive gain per joint), the loaded link's inertial columns and its mass column; the
+    total-least-squares solution is the right singular vector of the smallest singular value scaled to the known
+    payload mass."""
+    Wu, on_dev = to_device(W_b_u)
+    Wl, _ = to_device(W_b_l)
+    Wf, _ = to_device(W_l)
+    n_samples = param["nb_samples"]
+    nb_joints = int(len(I_u) / n_samples)
+    if len(I_u) != nb_joints * n_samples or len(I_l) != len(I_u):
+        raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
+    body = param["which_body_loaded"]
+    if param["has_friction"]:
+        stride, picks = 12, [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11]
+    elif param["has_actuator_inertia"]:
+        stride, picks = 14, [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13]
+    else:
+        stride, picks = 10, list(range(9))
+    width = stride if stride != 10 else 9
+    W_e_l = _payload_columns(Wf, body * stride, picks, width, param_standard_l, True)
+    if body * stride + 9 >= Wf.cols:
+        raise IndexError("index %d is out of bounds for axis 1 with size %d" % (body * stride + 9, Wf.cols))
+    return _total_regressor(Wu, Wl, Wf, I_u, I_l, nb_joints, n_samples, n_samples, W_e_l, body * stride + 9, param, on_dev)
+
+
+def build_total_regressor_wrench(W_b_u, W_b_l, W_l, tau_u, tau_l, param_standard_l, param):
+    """(W_tot, V_norm, residue) -- regressor.py:415-500: the external-wrench variant (six wrench components instead of
+    joints, no column elimination on the payload block)."""
+    Wu, on_dev = to_device(W_b_u)
+    Wl, _ = to_device(W_b_l)
+    Wf, _ = to_device(W_l)
+    n_u, n_l = int(len(tau_u) / 6), int(len(tau_l) / 6)
+    if len(tau_u) != 6 * n_u or len(tau_l) != 6 * n_l:
+        raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
+    body = param["which_body_loaded"]
+    W_e_l = _payload_columns(Wf, body * 10, list(range(9)), 9, param_standard_l, False)
+    if body * 10 + 9 >= Wf.cols:
+        raise IndexError("index %d is out of bounds for axis 1 with size %d" % (body * 10 + 9, Wf.cols))
+    return _total_regressor(Wu, Wl, Wf, tau_u, tau_l, 6, n_u, n_l, W_e_l, body * 10 + 9, param, on_dev)

@@ -113,6 +113,11 @@ int figh_colsq(const double *d_W, int64_t rows, int cols, int64_t ldw, double *d
  * column copies of build_baseRegressor / get_baseParams (qrdecomposition.py:223-236, :299-313). */
 int figh_gather_cols(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, double *d_out,
                      int64_t ldo);
+/* figh_place_block: dst[r][c] = scale * src[r][c], a rows x cols block between two row-major device matrices (the
+ * caller offsets the pointers) -- the np.concatenate / unary-minus / np.zeros statements that assemble W_tot in
+ * build_total_regressor_current / _wrench (regressor.py:316-412, :446-490). */
+int figh_place_block(const double *d_src, int64_t ld_src, int64_t rows, int64_t cols, double scale, double *d_dst,
+                     int64_t ld_dst);
 /* figh_matvec: y = W[:, col_idx] . x  (tau_base = np.dot(W_b, phi_b), e.g. staubli_TX40/identification.py:244) */
 int figh_matvec(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_x,
                 double *d_y);

@@ -81,6 +81,127 @@ def human_differentiation_fixture():
     print("human differentiation:", q2.shape, dq.shape, ddq.shape, "max |dq|", np.abs(dq).max())
 
 
+def sip_fixture():
+    """calculate_standard_parameters (identification_tools.py:466-572) run by the reference's own code; `quadprog` is
+    not installed, so its solve_qp is replaced by a recorder that (i) keeps the arguments the reference passes --
+    qp_G, qp_a, qp_C, qp_b, meq: every statement of the reference up to the solver call -- and (ii) returns the
+    solution of the same program from an independent method: all constraint rows are bounds on single variables, so
+    1/2 x^T G x - a^T x = 1/2 |L^T x - L^-1 a|^2 + const is a bounded-variable least-squares problem
+    (scipy.optimize.lsq_linear, BVLS).  COM bounds as examples/human/identification.py:598-612 derives them."""
+    from scipy import linalg, optimize
+    out = {}
+    for cfg, mname in (("cfg4_talos", "talos"), ("cfg5_human", "human")):
+        meta = json.load(open(os.path.join(GOLD, cfg + ".json")))
+        z = np.load(os.path.join(GOLD, cfg + ".npz"))
+        model = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", mname + ".json"))
+        W = oracle_np.build_regressor_basic(model.to_flat(), z["q_big"], z["v_big"], z["a_big"], meta["param"])
+        ids = [jj for jj in range(len(model.inertias.tolist())) if model.inertias.tolist()[jj].mass != 0]
+        cols = [14 * (jj - 1) + s for jj in ids for s in range(10)]
+        params_std = dict(zip(meta["names_std"], [float(x) for x in meta["phi_ref_raw"]]))
+        names = ("Ixx", "Ixy", "Ixz", "Iyy", "Iyz", "Izz", "mx", "my", "mz", "m")
+        phi_ref = np.array([params_std[j + str(k)] for k in ids for j in names])
+        COM_max, COM_min = [], []
+        for ii in range(len(ids)):
+            for kk in range(3):
+                x = phi_ref[10 * ii + 6 + kk]
+                if x > 0:
+                    COM_max.append(1.3 * x); COM_min.append(0.7 * x)
+                elif x < 0:
+                    COM_max.append(0.7 * x); COM_min.append(1.3 * x)
+                else:
+                    COM_max.append(0.001); COM_min.append(-0.001)
+        COM_max, COM_min = np.array(COM_max), np.array(COM_min)
+        rec = {}
+
+        def solve_qp(qp_G, qp_a, qp_C, qp_b, meq):
+            rec.update(qp_G=qp_G.copy(), qp_a=qp_a.copy(), qp_C=qp_C.copy(), qp_b=qp_b.copy(), meq=meq)
+            n = qp_a.shape[0]
+            lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+            for k in range(qp_C.shape[1]):  # C^T x >= b, one +-1 per column
+                (i,) = np.flatnonzero(qp_C[:, k])
+                if qp_C[i, k] > 0:
+                    lo[i] = max(lo[i], qp_b[k] / qp_C[i, k])
+                else:
+                    hi[i] = min(hi[i], qp_b[k] / qp_C[i, k])
+            L = np.linalg.cholesky(qp_G)
+            res = optimize.lsq_linear(L.T, linalg.solve_triangular(L, qp_a, lower=True), bounds=(lo, hi), method="bvls",
+                                      tol=1e-15, max_iter=5000)
+            rec.update(lo=lo, hi=hi, status=res.status)
+            return (res.x,)
+
+        gg.ref_idt.quadprog.solve_qp = solve_qp
+        alpha = 0.33
+        phi_std, phi_ref_out = gg.ref_idt.calculate_standard_parameters(model, W[:, cols], z["tau"], COM_max, COM_min,
+                                                                        params_std, alpha)
+        assert np.array_equal(phi_ref_out, phi_ref) and rec["status"] > 0
+        nact = int(((phi_std <= rec["lo"] + 1e-12) | (phi_std >= rec["hi"] - 1e-12)).sum())
+        print(cfg, "SIP QP:", len(phi_std), "variables,", rec["qp_C"].shape[1], "constraint rows,", nact, "active bounds")
+        pre = cfg + "/"
+        out.update({pre + "cols": np.array(cols), pre + "alpha": alpha, pre + "COM_max": COM_max, pre + "COM_min": COM_min,
+                    pre + "phi_ref": phi_ref, pre + "phi_standard": phi_std, pre + "qp_G": rec["qp_G"],
+                    pre + "qp_a": rec["qp_a"], pre + "qp_b": rec["qp_b"], pre + "meq": rec["meq"],
+                    # qp_C is a signed selection matrix: (row of the single non-zero, its value) per constraint
+                    pre + "qp_C_row": np.array([np.flatnonzero(rec["qp_C"][:, k])[0] for k in range(rec["qp_C"].shape[1])]),
+                    pre + "qp_C_val": np.array([rec["qp_C"][:, k].sum() for k in range(rec["qp_C"].shape[1])])})
+    np.savez_compressed(os.path.join(GOLD, "sip_qp.npz"), **out)
+
+
+def tls_fixture():
+    """build_total_regressor_current / _wrench (regressor.py:296-500) run by the reference's own code (pure NumPy)."""
+    out = {}
+    rng = np.random.default_rng(20250410 + 401)
+    # -- joint currents, TX40 (6 joints), the three column layouts the function distinguishes
+    cfg, mname = "cfg1_tx40", "tx40"
+    meta = json.load(open(os.path.join(GOLD, cfg + ".json")))
+    z = np.load(os.path.join(GOLD, cfg + ".npz"))
+    flat = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", mname + ".json")).to_flat()
+    W = oracle_np.build_regressor_basic(flat, z["q_big"], z["v_big"], z["a_big"], meta["param"])
+    W = oracle_np.add_coupling_TX40(W, len(z["q_big"]), z["v_big"], z["a_big"])
+    half, rows_u, rows_l, W_b_u, W_b_l, W_l = oracle_np.tls_inputs(W, z, 6)
+    gains = rng.uniform(20.0, 60.0, 6)
+    payload = rng.uniform(-0.5, 0.5, 14)
+    tau_u = z["tau"][rows_u]
+    tau_l = z["tau"][rows_l] + W_l[:, 5 * 14:5 * 14 + 14] @ payload
+    I_u = tau_u / np.repeat(gains, half) + 1e-3 * rng.standard_normal(6 * half)
+    I_l = tau_l / np.repeat(gains, half) + 1e-3 * rng.standard_normal(6 * half)
+    params_std = dict(zip(meta["names_std"], [float(x) for x in meta["phi_ref_raw"]]))
+    out["current/I_u"], out["current/I_l"] = I_u, I_l
+    for name, fr, ia in (("friction", True, True), ("actuator", False, True), ("plain", False, False)):
+        param = dict(meta["param"], has_friction=fr, has_actuator_inertia=ia, nb_samples=half, which_body_loaded=5,
+                     mass_load=3.0)
+        W_tot, V_norm, residue = gg.ref_reg.build_total_regressor_current(W_b_u, W_b_l, W_l, I_u, I_l, params_std, param)
+        sv = np.linalg.svd(W_tot, compute_uv=False)
+        print("TLS current/%s:" % name, W_tot.shape, "sigma_min %.3e, gap to the next %.3e" % (sv[-1], sv[-2]))
+        pre = "current/%s/" % name
+        out.update({pre + "shape": np.array(W_tot.shape), pre + "V_norm": V_norm, pre + "residue": residue,
+                    pre + "checksum": np.array([W_tot.sum(), np.abs(W_tot).sum()]), pre + "sv": sv})
+    # -- external wrench, human model
+    cfg, mname = "cfg5_human", "human"
+    meta = json.load(open(os.path.join(GOLD, cfg + ".json")))
+    z = np.load(os.path.join(GOLD, cfg + ".npz"))
+    flat = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", mname + ".json")).to_flat()
+    W = oracle_np.build_regressor_basic(flat, z["q_big"], z["v_big"], z["a_big"], meta["param"])
+    half, rows_u, rows_l, W_b_u, W_b_l, W_l = oracle_np.tls_inputs(W, z, 6, nbase=40)
+    # the wrench variant indexes W_l with 10 columns per link: the inertial columns only, as the human example passes them
+    W_l = W_l[:, [14 * k + s for k in range(W.shape[1] // 14) for s in range(10)]]
+    body = next(k for k in range(10, W_l.shape[1] // 10) if (np.abs(W_l[:, 10 * k:10 * k + 10]).sum(axis=0) > 0).all())
+    payload = rng.uniform(-0.5, 0.5, 10)
+    tau_u = z["tau"][rows_u] + 1e-3 * rng.standard_normal(6 * half)
+    tau_l = z["tau"][rows_l] + W_l[:, 10 * body:10 * body + 10] @ payload + 1e-3 * rng.standard_normal(6 * half)
+    params_std = dict(zip(meta["names_std"], [float(x) for x in meta["phi_ref_raw"]]))
+    param = dict(meta["param"], which_body_loaded=body, mass_load=2.0)
+    out["wrench/body"] = body
+    W_tot, V_norm, residue = gg.ref_reg.build_total_regressor_wrench(W_b_u, W_b_l, W_l, tau_u, tau_l, params_std, param)
+    sv = np.linalg.svd(W_tot, compute_uv=False)
+    print("TLS wrench:", W_tot.shape, "sigma_min %.3e, gap to the next %.3e" % (sv[-1], sv[-2]))
+    out.update({"wrench/tau_u": tau_u, "wrench/tau_l": tau_l, "wrench/shape": np.array(W_tot.shape),
+                "wrench/V_norm": V_norm, "wrench/residue": residue,
+                "wrench/checksum": np.array([W_tot.sum(), np.abs(W_tot).sum()]), "wrench/sv": sv})
+    np.savez_compressed(os.path.join(GOLD, "tls_regressors.npz"), **out)
+
+
 if __name__ == "__main__":
+    tls_fixture()
+    sip_fixture()
     qr_pivoting_fixture()
     human_differentiation_fixture()

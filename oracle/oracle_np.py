@@ -505,3 +505,20 @@ def qr_pivoting(tau, W_e, params_r, tol_qr=1e-8):
     phi_b = np.round(np.linalg.inv(R1) @ (Q1.T @ tau), 6)
     names = regroup_strings(sorted_names[:rank], sorted_names[rank:], beta)
     return Q1 @ R1, dict(zip(names, phi_b))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# test-data helper for the total-least-squares payload regressors (regressor.py:296-500, pure NumPy in the reference:
+# the fixture tests/golden/tls_regressors.npz is the reference's own output)
+def tls_inputs(W, z, nblocks, nbase=None):
+    """Unloaded / loaded data sets for the total-least-squares payload regressors, cut from one golden config: the first
+    half of the samples is the unloaded run, the second half the loaded one; the measurement vectors are the golden
+    tau of those rows, scaled by per-block gains, the loaded one carrying the contribution of a payload on the
+    picked columns plus noise.  Shared by the fixture generator and the tests (which rebuild W on the device)."""
+    N = len(z["q_big"])
+    half = N // 2
+    rows_u = np.concatenate([j * N + np.arange(half) for j in range(nblocks)])
+    rows_l = np.concatenate([j * N + half + np.arange(half) for j in range(nblocks)])
+    keep = [i for i in range(W.shape[1]) if i not in set(z["idx_e"].tolist())]
+    W_b = W[:, keep][:, z["idx_base"][:nbase]]  # nbase: only the leading base columns (few samples in the fixture)
+    return half, rows_u, rows_l, W_b[rows_u], W_b[rows_l], W[rows_l]

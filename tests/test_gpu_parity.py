@@ -764,6 +764,103 @@ def test_sip_qp_terms_match_reference_formulas(lib, golden):
     assert np.abs(r - r_ref).max() <= 1e-11 * np.abs(r_ref).max()
 
 
+def test_calculate_standard_parameters_matches_reference(lib, golden):
+    """calculate_standard_parameters (identification_tools.py:466-572) end to end: W of the inertial columns built and
+    reduced on the device, the program solved on the host, against the reference's own function (fixture
+    tests/golden/sip_qp.npz: its quadprog arguments and the solution of that program, oracle/gen_golden_extra.py)."""
+    from figaroh_plus_amd.identification import identification_tools as idt
+    g = golden
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sip_qp.npz"))
+    if g.name + "/cols" not in z.files:
+        if g.name == "cfg2_ur10":
+            # the base link is welded to the universe, whose inertia then has mass: the reference looks up 'Ixx0',
+            # which get_standard_parameters never writes -- KeyError there and here
+            W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+            with pytest.raises(KeyError):
+                idt.calculate_standard_parameters(g.robot().model, W[:, :60], g["tau"], np.ones(18), -np.ones(18),
+                                                  g.params_std(), 0.33)
+            return
+        pytest.skip("no SIP fixture for this config")
+    f = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(g.name + "/")}
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    Wc = np.ascontiguousarray(W[:, f["cols"]])
+    seen = {}
+    real = idt.quadprog_solve_qp
+
+    def spy(P, q, G=None, h=None, A=None, b=None):
+        seen.update(P=P, q=q)
+        return real(P, q, G, h, A, b)
+
+    idt.quadprog_solve_qp = spy
+    try:
+        phi, phi_ref = idt.calculate_standard_parameters(g.robot().model, Wc, g["tau"], f["COM_max"], f["COM_min"],
+                                                         g.params_std(), float(f["alpha"]))
+    finally:
+        idt.quadprog_solve_qp = real
+    assert np.array_equal(phi_ref, f["phi_ref"])
+    n = len(phi)
+    qp_G = 0.5 * (seen["P"] + seen["P"].T) + 1e-5 * np.eye(n)
+    assert np.abs(qp_G - f["qp_G"]).max() <= 1e-11 * np.abs(f["qp_G"]).max()
+    assert np.abs(-seen["q"] - f["qp_a"]).max() <= 1e-11 * np.abs(f["qp_a"]).max()
+    assert np.abs(phi - f["phi_standard"]).max() <= 1e-8 * np.abs(f["phi_standard"]).max()
+    with pytest.raises(ValueError):
+        idt.calculate_standard_parameters(g.robot().model, Wc[:, :-1], g["tau"], f["COM_max"], f["COM_min"],
+                                          g.params_std(), 0.33)
+
+
+# ------------------------------------------------------------------------------------------------ 8f-4 TLS payload
+def _tls_check(out, ref, pre, W_tot_rows):
+    W_tot, V_norm, residue = out
+    assert list(W_tot.shape) == ref[pre + "shape"].tolist()
+    cs = ref[pre + "checksum"]
+    assert abs(W_tot.sum() - cs[0]) <= 1e-10 * cs[1] and abs(np.abs(W_tot).sum() - cs[1]) <= 1e-11 * cs[1]
+    # the singular vector of the smallest singular value: conditioned by the gap to the next one (fixture: 3 % - 30x)
+    assert np.abs(V_norm - ref[pre + "V_norm"]).max() <= 1e-8 * np.abs(ref[pre + "V_norm"]).max()
+    assert np.abs(residue - ref[pre + "residue"]).max() <= 1e-8 * np.abs(ref[pre + "residue"]).max()
+
+
+def test_total_regressor_current_matches_reference(lib, golden_tx40, oracle_lib):
+    """build_total_regressor_current (regressor.py:296-412) against the output of the reference's own function
+    (tests/golden/tls_regressors.npz, oracle/gen_golden_extra.py) in its three column layouts; W_tot assembled on the
+    device, TLS vector from the SVD of its TSQR triangle, residue by a device mat-vec."""
+    from figaroh_plus_amd.device import GpuMatrix
+    from figaroh_plus_amd.tools.regressor import build_total_regressor_current
+    g = golden_tx40
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "tls_regressors.npz"))
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    half, rows_u, rows_l, W_b_u, W_b_l, W_l = oracle_np.tls_inputs(W, g.z, 6)
+    I_u, I_l = ref["current/I_u"], ref["current/I_l"]
+    for name, fr, ia in (("friction", True, True), ("actuator", False, True), ("plain", False, False)):
+        param = dict(g.param, has_friction=fr, has_actuator_inertia=ia, nb_samples=half, which_body_loaded=5, mass_load=3.0)
+        out = build_total_regressor_current(W_b_u, W_b_l, W_l, I_u, I_l, g.params_std(), param)
+        _tls_check(out, ref, "current/%s/" % name, 2 * len(W_l))
+    # device-resident inputs stay on the device
+    out = build_total_regressor_current(GpuMatrix.from_host(W_b_u), W_b_l, W_l, I_u, I_l, g.params_std(), param)
+    assert isinstance(out[0], GpuMatrix)
+    _tls_check((out[0].numpy(), out[1], out[2]), ref, "current/plain/", 2 * len(W_l))
+    # the reference's np.concatenate failures
+    with pytest.raises(ValueError):
+        build_total_regressor_current(W_b_u[:-1], W_b_l, W_l, I_u, I_l, g.params_std(), param)
+    with pytest.raises(ValueError):
+        build_total_regressor_current(W_b_u, W_b_l[:, :-1], W_l, I_u, I_l, g.params_std(), param)
+    with pytest.raises(IndexError):
+        build_total_regressor_current(W_b_u, W_b_l, W_l, I_u, I_l, g.params_std(), dict(param, which_body_loaded=9))
+
+
+def test_total_regressor_wrench_matches_reference(lib):
+    """build_total_regressor_wrench (regressor.py:415-500) on the human model, same fixture."""
+    from conftest import Golden
+    from figaroh_plus_amd.tools.regressor import build_total_regressor_wrench
+    g = Golden("cfg5_human")
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "tls_regressors.npz"))
+    W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
+    half, rows_u, rows_l, W_b_u, W_b_l, W_l = oracle_np.tls_inputs(W, g.z, 6, nbase=40)
+    W_l = np.ascontiguousarray(W_l[:, [14 * k + s for k in range(W.shape[1] // 14) for s in range(10)]])
+    param = dict(g.param, which_body_loaded=int(ref["wrench/body"]), mass_load=2.0)
+    out = build_total_regressor_wrench(W_b_u, W_b_l, W_l, ref["wrench/tau_u"], ref["wrench/tau_l"], g.params_std(), param)
+    _tls_check(out, ref, "wrench/", 2 * len(W_l))
+
+
 # ------------------------------------------------------------------------------------------------ flag sweep
 @pytest.mark.parametrize("flags", range(8))
 def test_regressor_all_flag_combinations(lib, golden, oracle_lib, flags):

@@ -149,3 +149,83 @@ def test_free_flyer_differentiation_matches_reference():
     d = joint_difference(model, z["q"][0], z["q"][1])
     assert np.abs(d[:3] - (z["q"][1, :3] - z["q"][0, :3])).max() > 1e-6
     assert np.abs(oracle_np.joint_difference(model.to_flat(), z["q"][0], z["q"][1]) - d).max() <= 1e-14
+
+
+# ------------------------------------------------------------------------------------------------ 8f-3 SIP program
+def _sip_fixture(cfg):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sip_qp.npz"))
+    g = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(cfg + "/")}
+    C = np.zeros((len(g["qp_a"]), len(g["qp_b"])))
+    C[g["qp_C_row"], np.arange(len(g["qp_b"]))] = g["qp_C_val"]
+    g["qp_C"] = C
+    return g
+
+
+def _kkt(G, a, C, b, meq, x, lag):
+    s = C.T @ x - b
+    return {"stationarity": np.abs(G @ x - a - C @ lag).max(),
+            "primal": max(0.0, -s[meq:].min() if len(s) > meq else 0.0, np.abs(s[:meq]).max() if meq else 0.0),
+            "dual": max(0.0, -lag[meq:].min()) if len(lag) > meq else 0.0,
+            "complementarity": np.abs(lag[meq:] * s[meq:]).max() if len(s) > meq else 0.0}
+
+
+def test_qp_solver_satisfies_kkt_on_random_programs():
+    """The host Goldfarb-Idnani solver (identification/qp.py, the reference's quadprog.solve_qp): for a strictly
+    convex program the KKT conditions are necessary and sufficient, so they pin the solution; equality rows, dependent
+    and never-active constraints, drops from the active set included."""
+    from figaroh_plus_amd.identification.qp import solve_qp
+    rng = np.random.default_rng(11)
+    removed = 0
+    for trial in range(40):
+        n = int(rng.integers(2, 40))
+        m = int(rng.integers(0, 60))
+        meq = int(rng.integers(0, min(n, m) // 2 + 1)) if m else 0
+        A = rng.standard_normal((n + 5, n))
+        G = A.T @ A + 0.1 * np.eye(n)
+        a = 3 * rng.standard_normal(n)
+        C = rng.standard_normal((n, m))
+        x0 = rng.standard_normal(n)
+        b = C.T @ x0 - rng.uniform(0, 1, m)
+        b[:meq] = C[:, :meq].T @ x0
+        x, f, xu, it, lag, iact = solve_qp(G, a, C, b, meq)
+        assert max(_kkt(G, a, C, b, meq, x, lag).values()) <= 1e-9, trial
+        assert abs(f - (0.5 * x @ G @ x - a @ x)) <= 1e-9 * (1 + abs(f))
+        assert np.abs(G @ xu - a).max() <= 1e-9 * np.abs(a).max()
+        assert sorted(iact.tolist()) == sorted((np.flatnonzero(lag != 0) + 1).tolist()) or len(iact) >= (lag != 0).sum()
+        removed += int(it[1])
+    assert removed > 0  # the sweep exercised the partial-step / drop branch
+    # quadprog's error behaviour
+    with pytest.raises(ValueError, match="positive definite"):
+        solve_qp(-np.eye(2), np.zeros(2))
+    with pytest.raises(ValueError, match="inconsistent"):
+        solve_qp(np.eye(2), np.zeros(2), np.array([[1.0, -1.0], [0.0, 0.0]]), np.array([1.0, 1.0]))  # x0 >= 1, x0 <= -1
+    x = solve_qp(np.eye(3), np.array([1.0, 2.0, 3.0]))[0]  # no constraints: the unconstrained minimiser
+    assert np.allclose(x, [1, 2, 3])
+
+
+@pytest.mark.parametrize("cfg", ["cfg4_talos", "cfg5_human"])
+def test_sip_program_against_reference_fixture(cfg):
+    """The SIP program of calculate_standard_parameters (identification_tools.py:466-572): tests/golden/sip_qp.npz holds
+    what the reference's own function hands to quadprog.solve_qp (recorded by oracle/gen_golden_extra.py) and the
+    solution of that program from an independent bounded-least-squares solve.  Host side of the mirror: the bound rows
+    G, h, quadprog_solve_qp's regularisation / sign conventions, and the solver."""
+    from figaroh_plus_amd.identification.identification_tools import quadprog_solve_qp, sip_constraints
+    from figaroh_plus_amd.identification.qp import solve_qp
+    g = _sip_fixture(cfg)
+    G, h = sip_constraints(g["phi_ref"], g["COM_max"], g["COM_min"])
+    assert np.array_equal(-G.T, g["qp_C"]) and np.array_equal(-h, g["qp_b"]) and int(g["meq"]) == 0
+    x, f, xu, it, lag, iact = solve_qp(g["qp_G"], g["qp_a"], g["qp_C"], g["qp_b"], 0)
+    scale = np.abs(g["phi_standard"]).max()
+    assert np.abs(x - g["phi_standard"]).max() <= 1e-10 * scale
+    assert max(_kkt(g["qp_G"], g["qp_a"], g["qp_C"], g["qp_b"], 0, x, lag).values()) <= 1e-12
+    # through the reference's wrapper: P, q with G x <= h (qp_G = 0.5 (P + P^T) + 1e-5 I, qp_a = -q)
+    n = len(x)
+    P = g["qp_G"] - 1e-5 * np.eye(n)
+    x2 = quadprog_solve_qp(P, -g["qp_a"], G, h)
+    assert np.abs(x2 - g["phi_standard"]).max() <= 1e-10 * scale
+    # an equality row through the wrapper (A x = b): total mass fixed to the reference's
+    A = np.zeros((1, n))
+    A[0, 9::10] = 1.0
+    bm = np.array([g["phi_ref"][9::10].sum()])
+    x3 = quadprog_solve_qp(P, -g["qp_a"], G, h, A, bm)
+    assert abs(x3[9::10].sum() - bm[0]) <= 1e-10 * bm[0] and (G @ x3 <= h + 1e-10 * scale).all()
