@@ -163,15 +163,17 @@ def exchange_from_env(prefer="rccl", device_key=None):
     all_ok = all(s[0] for s in states)
     distinct = len({s[2] for s in states}) == world
     # phase 2 (every rank takes part in the broadcast, whatever phase 1 said)
-    payload = [None]
-    if rank == 0 and all_ok and distinct:
-        try:
-            payload[0] = rccl_unique_id()
-        except Exception as e:  # noqa: BLE001
-            why = str(e)
+    payload = [None, ""]  # (unique id | None, why not) -- the reason travels with it so that every rank reports the same
+    if rank == 0:
+        if all_ok and distinct:
+            try:
+                payload[0] = rccl_unique_id()
+            except Exception as e:  # noqa: BLE001
+                payload[1] = str(e)
+        else:
+            payload[1] = "two ranks share a device" if all_ok else next(s[1] for s in states if not s[0])
     dist.broadcast_object_list(payload, src=0)
     if payload[0] is None:
-        reason = "two ranks share a device" if (all_ok and not distinct) else next((s[1] for s in states if not s[0]), why)
-        return TorchExchange(), {"collective": "torch.distributed/gloo host-staged (rccl unavailable: %s)" % reason[:80]}
+        return TorchExchange(), {"collective": "torch.distributed/gloo host-staged (rccl unavailable: %s)" % payload[1][:80]}
     # phase 3
     return RcclExchange(world, rank, payload[0]), {"collective": "rccl"}

@@ -75,6 +75,62 @@ def test_two_rank_exchange_matches_single_process(tmp_path, oracle_lib):
     assert np.abs(phi - g["phi_pinv"]).max() <= 1e-8 * np.abs(g["phi_pinv"]).max()
 
 
+def _setup_worker(rank, world, port, out_dir, scenario):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import json
+    import torch.distributed as dist
+    from figaroh_plus_amd import dist as fd
+
+    calls = {"unique_id": 0}
+    if scenario == "rank1_fails":      # librccl missing on ONE rank only
+        fd.rccl_preflight = lambda: (rank != 1, "simulated: librccl missing on rank 1" if rank == 1 else "")
+    elif scenario == "id_fails":       # every preflight passes, rank 0 cannot create the id
+        fd.rccl_preflight = lambda: (True, "")
+    elif scenario == "shared_device":  # both ranks name the same GPU
+        fd.rccl_preflight = lambda: (True, "")
+
+    def unique_id():
+        calls["unique_id"] += 1
+        raise RuntimeError("simulated: ncclGetUniqueId failed")
+
+    fd.rccl_unique_id = unique_id
+    key = ("box", 0) if scenario == "shared_device" else None
+    ex, info = fd.exchange_from_env("rccl", device_key=key)
+    # the fallback exchange must work right away on every rank: no rank is stuck in another collective
+    total = ex.allreduce_sum_host(np.array([float(rank + 1)]))
+    json.dump({"collective": info["collective"], "kind": type(ex).__name__, "sum": float(total[0]),
+               "unique_id_calls": calls["unique_id"]}, open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+    ex.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scenario", ["rank1_fails", "id_fails", "shared_device", "no_device"])
+def test_rccl_setup_is_decided_collectively(tmp_path, scenario):
+    """exchange_from_env (the RCCL set-up could deadlock on an asymmetric failure): preflight outcomes are
+    all-gathered, every rank takes part in the id broadcast, and all ranks take the same exchange.  Scenarios: the
+    preflight fails on one rank only; rank 0 fails to create the id after a clean preflight; two ranks name one device;
+    and the real preflight of this GPU-less container."""
+    import json
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_setup_worker, args=(2, port, str(tmp_path), scenario), nprocs=2, join=True)
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert res[0]["collective"] == res[1]["collective"] and "host-staged" in res[0]["collective"]
+    assert all(r["kind"] == "TorchExchange" and r["sum"] == 3.0 for r in res)
+    if scenario in ("rank1_fails", "shared_device", "no_device"):
+        assert res[0]["unique_id_calls"] == 0  # the id is only created after a clean, collective phase 1
+    if scenario == "rank1_fails":
+        assert "rank 1" in res[0]["collective"]
+    if scenario == "shared_device":
+        assert "share a device" in res[0]["collective"]
+    if scenario == "id_fails":
+        assert res[0]["unique_id_calls"] == 1 and res[1]["unique_id_calls"] == 0
+
+
 def test_shard_range_partitions():
     from figaroh_plus_amd.dist import shard_range
     for N in (0, 1, 7, 1000, 10 ** 6 + 3):
