@@ -606,6 +606,9 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
     FIGH_WY_CASE(8, 4, 4, 2)
 #ifdef FIGH_ABLATION
     FIGH_WY_CASE(8, 3, 4, 2)
+    FIGH_WY_CASE(4, 3, 4, 3)
+    FIGH_WY_CASE(4, 4, 3, 3)
+    FIGH_WY_CASE(4, 3, 3, 3)
     FIGH_WY_CASE(4, 4, 3, 2)
     FIGH_WY_CASE(8, 2, 4, 3)
     FIGH_WY_CASE(8, 2, 4, 2)
