@@ -136,9 +136,23 @@ class JointModel:
         self.nq, self.nv = _NQ[jtype], _NV[jtype]
 
     def shortname(self):
-        return {JT_REVOLUTE: "JointModelRevolute", JT_PRISMATIC: "JointModelPrismatic",
-                JT_CONTINUOUS: "JointModelRevoluteUnbounded", JT_FREEFLYER: "JointModelFreeFlyer",
-                JT_UNIVERSE: "JointModelUniverse"}[self.jtype]
+        """Pinocchio's joint model names: axis-aligned joints carry their axis (JointModelRZ, JointModelPX,
+        JointModelRUBY ...), anything else is the ...Unaligned variant."""
+        if self.jtype == JT_FREEFLYER:
+            return "JointModelFreeFlyer"
+        if self.jtype == JT_UNIVERSE:
+            return "JointModelUniverse"
+        a = np.asarray(self.axis, dtype=np.float64)
+        letter = None
+        for k, name in enumerate("XYZ"):
+            e = np.zeros(3)
+            e[k] = 1.0
+            if np.array_equal(a, e):
+                letter = name
+        if letter is None:
+            return {JT_REVOLUTE: "JointModelRevoluteUnaligned", JT_PRISMATIC: "JointModelPrismaticUnaligned",
+                    JT_CONTINUOUS: "JointModelRevoluteUnboundedUnaligned"}[self.jtype]
+        return "JointModel" + {JT_REVOLUTE: "R", JT_PRISMATIC: "P", JT_CONTINUOUS: "RUB"}[self.jtype] + letter
 
 
 class Data:

@@ -200,7 +200,46 @@ def tls_fixture():
     np.savez_compressed(os.path.join(GOLD, "tls_regressors.npz"), **out)
 
 
+def calibration_fixture():
+    """calculate_base_kinematics_regressor (calibration_tools.py:1469-1561) run by the reference's own module, loaded
+    by path inside a stand-in `figaroh` package (its relative imports resolve to the reference's regressor.py /
+    qrdecomposition.py); the calibration subsystem's kinematic regressor is replaced by
+    oracle_np.synthetic_kinematic_regressor."""
+    import importlib.util
+    import types
+    pkg, tools, cal = types.ModuleType("figaroh"), types.ModuleType("figaroh.tools"), types.ModuleType("figaroh.calibration")
+    for m in (pkg, tools, cal):
+        m.__path__ = []
+    sys.modules.update({"figaroh": pkg, "figaroh.tools": tools, "figaroh.calibration": cal,
+                        "figaroh.tools.regressor": gg.ref_reg, "figaroh.tools.qrdecomposition": gg.ref_qr})
+    spec = importlib.util.spec_from_file_location(
+        "figaroh.calibration.calibration_tools", os.path.join(gg.REF, "src/figaroh/calibration/calibration_tools.py"))
+    ref_cal = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_cal)
+    out = {}
+    rng = np.random.default_rng(5)
+    for case, mname, calib_model, free_flyer, zero_q in (("tx40_full", "tx40", "full_params", False, False),
+                                                         ("tx40_full_noq", "tx40", "full_params", False, True),
+                                                         ("talos_offsets", "talos", "joint_offset", True, False)):
+        model = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", mname + ".json"))
+        q = np.zeros((25, model.nq)) if zero_q else rng.uniform(-1, 1, (25, model.nq))
+        param = {"free_flyer": free_flyer, "calib_model": calib_model, "param_name": ["pre-existing"]}
+        ncols = 6 * (model.njoints - 1) if calib_model == "full_params" else model.nv
+        ref_cal.calculate_identifiable_kinematics_model = \
+            lambda q_, model_, data_, param_: oracle_np.synthetic_kinematic_regressor(q_, ncols, 11)
+        Rrand_b, R_b, R_e, names_base, names_e = ref_cal.calculate_base_kinematics_regressor(q, model, None, param)
+        out[case] = {"model": mname, "calib_model": calib_model, "free_flyer": free_flyer, "q": q.tolist(),
+                     "Rrand_b": [list(Rrand_b.shape), float(Rrand_b.sum()), float(np.abs(Rrand_b).sum())],
+                     "R_b": [list(R_b.shape), float(R_b.sum()), float(np.abs(R_b).sum())],
+                     "R_e": [list(R_e.shape), float(R_e.sum()), float(np.abs(R_e).sum())],
+                     "paramsrand_base": list(names_base), "paramsrand_e": list(names_e),
+                     "param_name": list(param["param_name"])}
+    with open(os.path.join(GOLD, "calibration_base_regressor.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
+    calibration_fixture()
     tls_fixture()
     sip_fixture()
     qr_pivoting_fixture()

@@ -522,3 +522,21 @@ def tls_inputs(W, z, nblocks, nbase=None):
     keep = [i for i in range(W.shape[1]) if i not in set(z["idx_e"].tolist())]
     W_b = W[:, keep][:, z["idx_base"][:nbase]]  # nbase: only the leading base columns (few samples in the fixture)
     return half, rows_u, rows_l, W_b[rows_u], W_b[rows_l], W[rows_l]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# test-data helper for calculate_base_kinematics_regressor (calibration_tools.py:1469-1561): a stand-in for the
+# calibration subsystem's kinematic regressor with the features the reduction has to deal with -- columns that do not
+# affect the measurements (exact zeros) and columns that are linear combinations of others
+def synthetic_kinematic_regressor(q, ncols, seed):
+    nposes = 40 if len(q) == 0 else len(q)
+    rng = np.random.default_rng(seed + 7 * nposes)
+    R = rng.standard_normal((3 * nposes, ncols))
+    struct = np.random.default_rng(seed)  # the structure depends on the model only, not on the poses
+    zero = struct.choice(ncols, size=max(1, ncols // 6), replace=False)
+    R[:, zero] = 0.0
+    free = [c for c in range(ncols) if c not in set(zero.tolist())]
+    for k in range(max(1, ncols // 8)):
+        a, b, c = struct.choice(free, size=3, replace=False)
+        R[:, c] = 0.5 * R[:, a] - 2.0 * R[:, b]
+    return R

@@ -861,6 +861,43 @@ def test_total_regressor_wrench_matches_reference(lib):
     _tls_check(out, ref, "wrench/", 2 * len(W_l))
 
 
+@pytest.mark.parametrize("case", ["tx40_full", "tx40_full_noq", "talos_offsets"])
+def test_calibration_base_regressor_matches_reference(lib, case, capsys):
+    """calculate_base_kinematics_regressor (calibration_tools.py:1469-1561), the second caller of the elimination /
+    base-parameter functions, against the output of the reference's own function (fixture
+    tests/golden/calibration_base_regressor.json, oracle/gen_golden_extra.py; the calibration subsystem's kinematic
+    regressor is the same synthetic stand-in on both sides): names, expressions, shapes, matrices, the side effect on
+    param["param_name"] and the printed shapes."""
+    import json
+    from figaroh_plus_amd.calibration.calibration_tools import calculate_base_kinematics_regressor
+    from figaroh_plus_amd.tools.robot import Robot
+    with open(os.path.join(os.path.dirname(__file__), "golden", "calibration_base_regressor.json")) as f:
+        ref = json.load(f)[case]
+    model = Robot.from_flat(ref["model"]).model
+    q = np.array(ref["q"])
+    param = {"free_flyer": ref["free_flyer"], "calib_model": ref["calib_model"], "param_name": ["pre-existing"]}
+    ncols = 6 * (model.njoints - 1) if ref["calib_model"] == "full_params" else model.nv
+    calls = []
+
+    def kin(q_, model_, data_, param_):
+        calls.append(len(q_))
+        return oracle_np.synthetic_kinematic_regressor(q_, ncols, 11)
+
+    Rrand_b, R_b, R_e, names_base, names_e = calculate_base_kinematics_regressor(q, model, None, param,
+                                                                                 kinematics_model=kin)
+    assert names_base == ref["paramsrand_base"] and names_e == ref["paramsrand_e"]
+    assert param["param_name"] == ref["param_name"]
+    for got, key in ((Rrand_b, "Rrand_b"), (R_b, "R_b"), (R_e, "R_e")):
+        shape, total, abstotal = ref[key]
+        assert list(got.shape) == shape
+        assert abs(got.sum() - total) <= 1e-12 * abstotal and abs(np.abs(got).sum() - abstotal) <= 1e-12 * abstotal
+    # random-configuration regressor from [] for a fixed base, from q for a free-flyer; the given one only if q != 0
+    assert calls == ([len(q)] if ref["free_flyer"] else [0]) + ([len(q)] if np.any(q) else [])
+    assert "shape of full regressor, reduced regressor, base regressor:" in capsys.readouterr().out
+    with pytest.raises(NotImplementedError):
+        calculate_base_kinematics_regressor(q, model, None, dict(param))
+
+
 # ------------------------------------------------------------------------------------------------ flag sweep
 @pytest.mark.parametrize("flags", range(8))
 def test_regressor_all_flag_combinations(lib, golden, oracle_lib, flags):

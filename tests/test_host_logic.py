@@ -229,3 +229,25 @@ def test_sip_program_against_reference_fixture(cfg):
     bm = np.array([g["phi_ref"][9::10].sum()])
     x3 = quadprog_solve_qp(P, -g["qp_a"], G, h, A, bm)
     assert abs(x3[9::10].sum() - bm[0]) <= 1e-10 * bm[0] and (G @ x3 <= h + 1e-10 * scale).all()
+
+
+def test_calibration_parameter_names():
+    """get_geo_offset / get_joint_offset (calibration_tools.py:252-331): six placement offsets per joint, one joint
+    offset per degree of freedom named after Pinocchio's joint model (axis-aligned: RZ, PX, RUBZ ...; multi-dof joints
+    number their entries from the second one)."""
+    from figaroh_plus_amd.calibration.calibration_tools import get_geo_offset, get_joint_offset
+    from figaroh_plus_amd.tools.robot import Robot
+    m = Robot.from_flat("tx40").model
+    geo = get_geo_offset(list(m.names[1:]))
+    assert list(geo)[:7] == ["d_px_joint_1", "d_py_joint_1", "d_pz_joint_1", "d_phix_joint_1", "d_phiy_joint_1",
+                             "d_phiz_joint_1", "d_px_joint_2"] and set(geo.values()) == {0}
+    assert list(get_joint_offset(m, m.names[1:])) == ["offsetRZ_joint_%d" % k for k in range(1, 7)]
+    t = Robot.from_flat("talos").model
+    off = list(get_joint_offset(t, t.names[1:]))
+    assert off[:7] == ["offsetFreeFlyer_root_joint"] + ["offsetFreeFlyer%d_root_joint" % k for k in range(2, 7)] + \
+        ["offsetRZ_leg_left_1_joint"] and len(off) == t.nv
+    # the fixture's names were produced by the reference's own get_geo_offset / get_joint_offset
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "calibration_base_regressor.json")))
+    assert set(ref["tx40_full"]["paramsrand_e"]) <= set(geo)
+    assert set(ref["talos_offsets"]["paramsrand_e"]) <= set(off)
