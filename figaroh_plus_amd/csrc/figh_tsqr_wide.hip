@@ -260,7 +260,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     FIGH_PROF_DECL
     if constexpr (WPE == 1) asm volatile("" ::: "a255");  // the allocation covers the SIMD: never two waves on one
     constexpr int RPL = 4 * NRC, M = 16 * NRC, VBUF = M * kLdv + 16 * kLdt, NQ = CPW - 1;
-    __shared__ double vt[2][VBUF];      // ping-pong: V (M x kLdv) followed by T (16 x kLdt)
+    __shared__ double vt[3][VBUF];      // V (M x kLdv) followed by T (16 x kLdt); three buffers: panel p is still read in
+                                        // phase p + 1 (deferred sweep of the wave that factored panel p + 1)
     __shared__ double rpp[NW][256];     // the diagonal block of the panel a wave is factoring (wave-private)
     __shared__ double redbuf[NW][64];   // cross-row-group sums (wave-private)
     __shared__ int fnz[2][NW];
@@ -429,10 +430,13 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         while (front < p0 && front < wave + NW * CPW) FIGH_WY_RETIRE(rn);
 
         if (p0 < nch) {
+            int vb = p0 % 3;        // V/T buffer of panel p (wave-uniform); vbp: the buffer of panel p - 1
+            int vbp = vb;
+            bool deferred = false;  // this wave factored panel p in phase p - 1 and owes its other chunks panel p - 1
             // ---- the first panel of the tile has nobody to overlap with
             if (wave == (p0 & (NW - 1))) {
                 __builtin_amdgcn_s_setprio(3);
-                double *Vn = vt[p0 & 1];
+                double *Vn = vt[vb];
                 double *bpp = block(p0, p0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = bpp[lane + 64 * r];
@@ -460,8 +464,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
             f64x4 rp_next = {0.0, 0.0, 0.0, 0.0};
             bool have_next = false;
             for (int p = p0; p + 1 < nch; ++p) {
-                const double *Vl = vt[p & 1];
+                const double *Vl = vt[vb];
                 const double *Tl = Vl + M * kLdv;
+                const int vbn = vb == 2 ? 0 : vb + 1;
                 const int pn = p + 1;
                 f64x4 rp = rp_next;
                 const bool have = have_next;
@@ -472,7 +477,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     for (int r = 0; r < 4; ++r) rp_next[r] = b1[lane + 64 * r];
                     have_next = true;
                 }
-                if (wave == (pn & (NW - 1))) {  // front == pn
+                const bool is_owner = wave == (pn & (NW - 1));
+                if (is_owner) {  // front == pn
                     // this wave is the critical path of the workgroup until panel p + 1 is published: it wins the
                     // issue arbitration against the waves it shares the SIMD with
                     __builtin_amdgcn_s_setprio(3);
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     FIGH_PROF_ADD(3);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = rq[r];
-                    double *Vn = vt[pn & 1];
+                    double *Vn = vt[vbn];
                     double X[RPL];
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) X[i] = F.t[i >> 2][i & 3];
@@ -503,31 +509,48 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     FIGH_WY_RETIRE(rn);
                     __builtin_amdgcn_s_setprio(0);
                     FIGH_PROF_ADD(11);
+                    // LOAD BALANCE: the look-ahead (chunk update + 16 dependent column steps) is about two trailing
+                    // sweeps long, so this wave leaves panel p to its other chunks for the next phase, when it is not
+                    // the owner (NW >= 2) -- otherwise every phase lasts look-ahead + sweep and the other waves wait at
+                    // the barrier for half of it (in-kernel profile before the change: 44 % of the wave time).
+                    deferred = true;
                 }
-                // every chunk behind panel p + 1 (the owner's queue has already moved on: its F is its next chunk)
-                if (front > pn && front < nch) {
-                    double *b = block(p, front);
-                    f64x4 rb;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rb[r] = b[lane + 64 * r];
-                    wy_update_chunk<NRC>(F.t, Vl, Tl, rb, b, lane, c, g);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: hoisting the next chunk's operands costs registers
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const int cc = front + NW * (j + 1);
-                    if (cc > pn && cc < nch) {
-                        double *b = block(p, cc);
+                // Trailing sweeps of this wave in this phase -- ONE copy of the update code in a wave-uniform loop (a
+                // second copy costs hundreds of spilled registers): none for the owner, panel p - 1 and then panel p for
+                // last phase's owner, panel p for everybody else.
+                const bool owe = deferred && !is_owner;
+#pragma nounroll
+                for (int rep = is_owner ? 2 : (owe ? 0 : 1); rep < 2; ++rep) {
+                    const int pp = rep == 0 ? p - 1 : p;  // the panel applied in this sweep, to the chunks behind pp + 1
+                    const double *Vx = rep == 0 ? vt[vbp] : Vl;
+                    const double *Tx = Vx + M * kLdv;
+                    if (front > pp + 1 && front < nch) {
+                        double *b = block(pp, front);
                         f64x4 rb;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) rb[r] = b[lane + 64 * r];
-                        wy_update_chunk<NRC>(Q[j].t, Vl, Tl, rb, b, lane, c, g);
+                        wy_update_chunk<NRC>(F.t, Vx, Tx, rb, b, lane, c, g);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: hoisting the next chunk's operands costs registers
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const int cc = front + NW * (j + 1);
+                        if (cc > pp + 1 && cc < nch) {
+                            double *b = block(pp, cc);
+                            f64x4 rb;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) rb[r] = b[lane + 64 * r];
+                            wy_update_chunk<NRC>(Q[j].t, Vx, Tx, rb, b, lane, c, g);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+                if (owe) deferred = false;
                 FIGH_PROF_ADD(5);
                 __syncthreads();
                 FIGH_PROF_ADD(6);
+                vbp = vb;
+                vb = vbn;
             }
         }
         // slots beyond the last chunk of the matrix (and, for a zero tile, everything) leave the queue unused
