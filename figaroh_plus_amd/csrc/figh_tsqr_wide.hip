@@ -319,12 +319,17 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     const unsigned toff = 8u * (unsigned)g;
     const unsigned ldw8 = 8u * (unsigned)ldw;  // bytes per row (the host side guarantees 64 * ldw * 8 < 2^32)
 
-    // requests for the chunk of slot S_ in the FULL tile at row r0_: RPL independent loads per lane
+    // requests for the chunk of slot S_ in the tile at row r0_: RPL independent loads per lane.  The descriptor ends
+    // with the matrix, so the rows of a ragged last tile beyond `rows` come back as zeros from the buffer range check
+    // -- no second, clamped-and-masked load path (whose 64-bit row arithmetic the compiler hoisted into scratch).
 #define FIGH_WY_LOAD(S_, r0_)                                                                                     \
     do {                                                                                                          \
+        const long left_ = rows - (r0_);                                                                          \
         if ((S_).wlive) {                                                                                         \
+            const long bytes_ = left_ * ldw * 8;                                                                  \
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
-                const_cast<double *>(W + (r0_) * ldw), (short)0, 0x7fffffff, 0x00020000);                         \
+                const_cast<double *>(W + (r0_) * ldw), (short)0, (int)(bytes_ < 0x7fffffffL ? bytes_ : 0x7fffffffL), \
+                0x00020000);                                                                                      \
             _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                     \
                 const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(                                            \
                     rs_, (S_).boff, (unsigned)(16 * (i >> 2) + 4 * (i & 3)) * ldw8, 0);                           \
@@ -333,7 +338,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         }                                                                                                         \
         if ((S_).tlive) {                                                                                         \
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
-                const_cast<double *>(tau + (r0_)), (short)0, 0x7fffffff, 0x00020000);                             \
+                const_cast<double *>(tau + (r0_)), (short)0, (int)(left_ * 8 < 0x7fffffffL ? left_ * 8 : 0x7fffffffL), \
+                0x00020000);                                                                                      \
             _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                     \
                 const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(                                            \
                     rs_, toff, 8u * (unsigned)(16 * (i >> 2) + 4 * (i & 3)), 0);                                  \
@@ -341,16 +347,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
-    // the last, ragged tile: rows clamped, then masked
-#define FIGH_WY_LOAD_RAGGED(S_, r0_)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < RPL; ++i) {                                                             \
-        const long row_ = (r0_) + 16 * (i >> 2) + 4 * (i & 3) + g;                                                \
-        const long rowc_ = row_ < rows ? row_ : rows - 1;                                                         \
-        double val_ = 0.0;                                                                                        \
-        if ((S_).wlive) val_ = W[rowc_ * ldw + (S_).wcol];                                                        \
-        if ((S_).tlive) val_ = tau[rowc_];                                                                        \
-        (S_).t[i >> 2][i & 3] = row_ < rows ? val_ : 0.0;                                                         \
-    }
 #define FIGH_WY_WAVE_SYNC()                                    \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -381,17 +377,11 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x, parity ^= 1) {
         const long r0 = t * M;
         const long r0n = (t + gridDim.x) * M;
-        const bool next_full = r0n + M <= rows;  // only full tiles are prefetched
+        const bool next_full = r0n < rows;  // the workgroup has another tile (full or ragged: the descriptor zero-fills)
         if (!prefetched) {
-            if (r0 + M <= rows) {
-                FIGH_WY_LOAD(F, r0);
+            FIGH_WY_LOAD(F, r0);
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) FIGH_WY_LOAD(Q[j], r0);
-            } else {
-                FIGH_WY_LOAD_RAGGED(F, r0)
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) { FIGH_WY_LOAD_RAGGED(Q[j], r0) }
-            }
+            for (int j = 0; j < NQ; ++j) FIGH_WY_LOAD(Q[j], r0);
         }
         prefetched = next_full;
         if (blkw) {  // row-block weights (WLS): row r is scaled by blkw[r / rows_per_blk]
@@ -558,7 +548,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         front = wave;
     }
 #undef FIGH_WY_LOAD
-#undef FIGH_WY_LOAD_RAGGED
 #undef FIGH_WY_WAVE_SYNC
 #undef FIGH_WY_RETIRE
     FIGH_PROF_STORE(prof, wave, NW);
