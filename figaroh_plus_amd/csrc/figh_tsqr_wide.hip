@@ -260,6 +260,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     FIGH_PROF_DECL
     if constexpr (WPE == 1) asm volatile("" ::: "a255");  // the allocation covers the SIMD: never two waves on one
     constexpr int RPL = 4 * NRC, M = 16 * NRC, VBUF = M * kLdv + 16 * kLdt, NQ = CPW - 1;
+    constexpr bool kLateRetire = CPW <= 4;  // see the look-ahead block
     __shared__ double vt[3][VBUF];      // V (M x kLdv) followed by T (16 x kLdt); three buffers: panel p is still read in
                                         // phase p + 1 (deferred sweep of the wave that factored panel p + 1)
     __shared__ double rpp[NW][256];     // the diagonal block of the panel a wave is factoring (wave-private)
@@ -440,12 +441,17 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                 FIGH_PROF_ADD(9);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
-                FIGH_WY_RETIRE(rn);
+                if constexpr (!kLateRetire) FIGH_WY_RETIRE(rn);
                 __builtin_amdgcn_s_setprio(0);
-                FIGH_PROF_ADD(10);
             }
             __syncthreads();
             FIGH_PROF_ADD(2);
+            if constexpr (kLateRetire) {
+                if (wave == (p0 & (NW - 1))) {
+                    FIGH_WY_RETIRE(rn);
+                    FIGH_PROF_ADD(10);
+                }
+            }
 
             // ---- phase p: apply panel p to the trailing chunks; the owner of chunk p + 1 updates that chunk first and
             // factors panel p + 1 meanwhile.  The block (p, p+1) of the triangle that the owner starts with was requested
@@ -496,9 +502,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     FIGH_PROF_ADD(4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
-                    FIGH_WY_RETIRE(rn);
+                    // the queue rotation + the requests for the next tile's chunk (0.4-0.9 k cycles): with few slots per
+                    // wave after the barrier, where nobody waits for them (same-box A/B: n = 191 +4 %); with six slots
+                    // the rotation is long and last phase's owner, who has two sweeps to do, is the critical wave
+                    // (TALOS -3 %), so there it stays in front of the barrier
+                    if constexpr (!kLateRetire) FIGH_WY_RETIRE(rn);
                     __builtin_amdgcn_s_setprio(0);
-                    FIGH_PROF_ADD(11);
                     // LOAD BALANCE: the look-ahead (chunk update + 16 dependent column steps) is about two trailing
                     // sweeps long, so this wave leaves panel p to its other chunks for the next phase, when it is not
                     // the owner (NW >= 2) -- otherwise every phase lasts look-ahead + sweep and the other waves wait at
@@ -539,6 +548,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                 FIGH_PROF_ADD(5);
                 __syncthreads();
                 FIGH_PROF_ADD(6);
+                if constexpr (kLateRetire) {
+                    if (is_owner) {
+                        FIGH_WY_RETIRE(rn);
+                        FIGH_PROF_ADD(11);
+                    }
+                }
                 vbp = vb;
                 vb = vbn;
             }

@@ -25,6 +25,13 @@ pipe = IdentificationPipeline(robot, meta["param"], params_std=dict(zip(meta["na
 pipe.set_samples(q, v, a)
 pipe.set_tau_from_parameters(np.array([float(x) for x in meta["phi_ref_raw"]]), noise_std=0.0, seed=0)
 pipe.run(); _lib.synchronize()
+_lib.profile_enable(True, level=1); _lib.profile_reset()
+for _ in range(steps):
+    pipe.run()
+_lib.synchronize()
+print("kernel averages (HIP events):", {k: round(_lib.profile_get(k)[1] / max(_lib.profile_get(k)[0], 1), 3)
+                                        for k in ("regressor_tree", "regressor_chain", "tsqr")})
+_lib.profile_enable(False)
 t0 = time.perf_counter()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(steps):
