@@ -41,6 +41,9 @@ class _View:
         self.ptr = base.ptr + int(byte_offset)
 
 
+from ._host import single_threaded_blas as _single_threaded_blas
+
+
 def _dtrtri(R1):
     from scipy.linalg.lapack import dtrtri
     return dtrtri(R1, lower=0)  # reads the upper triangle only
@@ -261,10 +264,12 @@ class IdentificationPipeline:
         R1, R2, z = R_r[:r, :r], R_r[:r, r:n], (R_r[:r, n] if with_tau else None)
         # inv(R1) of qrdecomposition.py:244 by LAPACK's triangular inverse (dtrtri): R1 is upper triangular, and
         # np.linalg.inv's general LU path pays ~30 us of BLAS thread start-up per call on a many-core host
-        R1_inv, info = _dtrtri(R1)
-        if info != 0:
-            raise np.linalg.LinAlgError("Singular matrix")
-        beta = np.around(R1_inv @ R2, 6)
+        with _single_threaded_blas(n):
+            R1_inv, info = _dtrtri(R1)
+            if info != 0:
+                raise np.linalg.LinAlgError("Singular matrix")
+            beta = np.around(R1_inv @ R2, 6)
+            phi_ls = R1_inv @ z if with_tau else None
         out = {
             "idx_e": idx_e, "params_r": params_r, "idx_base": idx_base, "beta": beta,
             "col_norm": col_norm, "absdiagR": np.abs(np.diag(R)[:n]), "rows": total_rows,
@@ -273,7 +278,7 @@ class IdentificationPipeline:
             out["params_base"] = qrd._expressions([params_r[i] for i in idx_base],
                                                   [params_r[i] for i in idx_regroup], beta)
         if with_tau:
-            out["phi_b"] = np.round(R1_inv @ z, 6)
-            out["phi_ls"] = R1_inv @ z
+            out["phi_b"] = np.round(phi_ls, 6)
+            out["phi_ls"] = phi_ls
             out["residual_norm"] = abs(R[n, n])
         return out

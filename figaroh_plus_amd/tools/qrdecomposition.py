@@ -12,6 +12,7 @@ and the expression strings follow the reference statement by statement.
 import numpy as np
 
 from .. import _lib
+from .._host import single_threaded_blas
 from ..device import GpuMatrix, index_to_device, to_device, vector_to_device
 
 TOL_QR = 1e-8
@@ -94,7 +95,8 @@ def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
     R = rfactor(Wd)
     idx_base, idx_regroup = _select(np.diag(R), params_r, tol_qr)
     R1, R2, _ = _regroup(R, idx_base, idx_regroup, False)
-    beta = np.around(np.matmul(np.linalg.inv(R1), R2), 6)
+    with single_threaded_blas():  # n x n host work: see _host.py
+        beta = np.around(np.matmul(np.linalg.inv(R1), R2), 6)
     params_base = _expressions([params_r[i] for i in idx_base], [params_r[i] for i in idx_regroup], beta)
     # W_b = Q1 R1 is by construction the gathered base columns (the reference asserts it, :268-269)
     W_b = _base_columns(Wd, idx_base, on_dev)
@@ -110,9 +112,10 @@ def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR):
     idx_base, idx_regroup = _select(np.diag(R)[:n], params_r, tol_qr)
     numrank_W = len(idx_base)
     R1, R2, q1t_tau = _regroup(R, idx_base, idx_regroup, True)
-    R1_inv = np.linalg.inv(R1)
-    beta = np.around(np.dot(R1_inv, R2), 6)
-    phi_b = np.round(np.dot(R1_inv, q1t_tau), 6)
+    with single_threaded_blas():
+        R1_inv = np.linalg.inv(R1)
+        beta = np.around(np.dot(R1_inv, R2), 6)
+        phi_b = np.round(np.dot(R1_inv, q1t_tau), 6)
     W_b = _base_columns(Wd, idx_base, on_dev)
     params_base = [params_r[i] for i in idx_base]
     params_regroup = [params_r[i] for i in idx_regroup]
