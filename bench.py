@@ -27,23 +27,77 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: fp64 vector == fp64 matrix (v_mfma
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup quota if there is one (the GPU boxes show 256 logical CPUs under a
+    quota of 16), else None.  Threads beyond the quota do not add throughput, they get the whole process frozen until
+    the next accounting period."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2
+            quota, period = f.read().split()
+        if quota != "max":
+            return float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:  # cgroup v1
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        if quota > 0:
+            return quota / period
+    except Exception:
+        pass
+    return None
+
+
+def _baseline_threads():
+    """Thread cap for the CPU baseline legs: the quota when there is one (so the baseline is not throttled)."""
+    quota = cpu_quota()
+    if quota is None:
+        return None
+    n = max(1, int(quota))
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))  # the OpenMP regressor of oracle/ (read when its runtime starts)
+    return n
+
+
+class _Threads:
+    def __init__(self, n):
+        self.n, self.ctx = n, None
+
+    def __enter__(self):
+        if self.n:
+            try:
+                from threadpoolctl import threadpool_limits
+                self.ctx = threadpool_limits(limits=self.n)
+            except Exception:
+                self.ctx = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.restore_original_limits()
+        return False
+
+
 def cpu_baseline(flat, seed, n_cpu):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    cap = _baseline_threads()
     import cpu_baseline as cb  # oracle: measured here as the reported baseline, never shipped
 
     rng = np.random.default_rng(seed)
     q, v, a = (rng.uniform(-6, 6, (n_cpu, 6)) for _ in range(3))
     tau = rng.standard_normal(6 * n_cpu)
-    t0 = time.perf_counter()
-    _, stages = cb.faithful_pass(flat, q, v, a, tau)
-    dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        blas = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        blas = os.cpu_count()
+    with _Threads(cap):
+        t0 = time.perf_counter()
+        _, stages = cb.faithful_pass(flat, q, v, a, tau)
+        dt = time.perf_counter() - t0
+        try:
+            from threadpoolctl import threadpool_info
+            blas = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        except Exception:
+            blas = os.cpu_count()
     return {
-        "value": n_cpu / dt, "unit": "samples/s", "cores": int(blas), "kind": "port",
+        "value": n_cpu / dt, "unit": "samples/s", "cores": int(blas), "cpu_quota_cpus": cpu_quota(), "kind": "port",
         "sample": "%d of the 1e6 UR10 samples, faithful reference structure (python per-sample loop around the C "
                   "regressor of oracle/, numpy scatter+permutation, np.diag(W.T@W), np.delete, 2x np.linalg.qr, "
                   "pinv); host has %d logical cpus, BLAS threads %d; stage seconds %s" % (
@@ -59,14 +113,18 @@ def cpu_baseline_fast(flat, seed, n_cpu):
     rng = np.random.default_rng(seed)
     q, v, a = (rng.uniform(-6, 6, (n_cpu, 6)) for _ in range(3))
     tau = rng.standard_normal(6 * n_cpu)
-    cb.fast_pass(flat, q[:2000], v[:2000], a[:2000], tau[:12000])  # thread pools up
-    t0 = time.perf_counter()
-    _, stages = cb.fast_pass(flat, q, v, a, tau)
-    dt = time.perf_counter() - t0
-    return {"value": n_cpu / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+    cap = _baseline_threads()
+    with _Threads(cap):
+        cb.fast_pass(flat, q[:2000], v[:2000], a[:2000], tau[:12000])  # thread pools up
+        t0 = time.perf_counter()
+        _, stages = cb.fast_pass(flat, q, v, a, tau)
+        dt = time.perf_counter() - t0
+    return {"value": n_cpu / dt, "unit": "samples/s", "cores": cap or os.cpu_count(), "cpu_quota_cpus": cpu_quota(),
+            "kind": "port",
             "sample": "%d of the 1e6 UR10 samples, fair-fast structure (one OpenMP C call for the batch regressor, einsum "
                       "column norms, np.linalg.qr(mode='r') of [W_e tau], regrouped QR of the triangle, triangular solves); "
-                      "stage seconds %s" % (n_cpu, {k: round(x, 2) for k, x in stages.items()})}
+                      "host has %d logical cpus, threads capped at the cgroup quota when there is one; stage seconds %s" % (
+                          n_cpu, os.cpu_count(), {k: round(x, 2) for k, x in stages.items()})}
 
 
 CONFIGS = {  # BASELINE.json configs[1..4]: (golden fixture, model, samples in the config, chunk for the streamed pass)
