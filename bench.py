@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--host-wait", default=None, choices=["spin", "block"],
+                    help="how the host waits for the GPU: spin (default for one GPU) or block = interrupt-driven (default "
+                         "for several ranks on a node: spinning ranks can exhaust a container's CPU quota)")
     args = ap.parse_args()
 
     # the shipped library has no run-time switches; FIGH_LIB_PATH would swap in another build (tools/ A/B runs only)
@@ -172,6 +175,8 @@ def main():
     lib = _lib.load()
     if _lib.device_count() == 0:
         raise SystemExit("bench.py needs a HIP device: libfigh has no CPU path")
+    host_wait = args.host_wait or ("block" if world > 1 else "spin")
+    _lib.check(lib.figh_host_wait_mode(1 if host_wait == "block" else 0))
     _lib.check(lib.figh_device_set(local_rank % _lib.device_count()))
     exchange, xinfo = exchange_from_env(args.exchange)
 
@@ -343,7 +348,7 @@ def main():
                 "base_parameters": len(out["idx_base"]), "collective": xinfo["collective"], "ranks": world,
                 "rank0_seconds": dt_rank, "max_rank_seconds": dt,
                 "device": _lib.device_info()["name"], "result_matches_reference": bool(ok),
-                "figh_env": "none set (checked)",
+                "figh_env": "none set (checked)", "host_wait": host_wait,
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
             "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},

@@ -39,6 +39,8 @@ void set_error(const std::string &msg) { g_error = msg; }
 
 hipStream_t stream() { return g_stream; }
 
+static bool g_blocking_wait = false;
+
 int ensure_device() {
     if (g_ready) return FIGH_OK;
     int n = 0;
@@ -124,7 +126,18 @@ int figh_device_count(int *count) {
 int figh_device_set(int device) {
     FIGH_REQUIRE(!g_ready, "figh_device_set must be called before any other device call");
     FIGH_HIP(hipSetDevice(device));
+    if (g_blocking_wait) {
+        // must precede the creation of the device's context; a process that already has one keeps its mode
+        const hipError_t e = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
     return ensure_device();
+}
+
+int figh_host_wait_mode(int blocking) {
+    FIGH_REQUIRE(!g_ready, "figh_host_wait_mode must be called before any device call");
+    g_blocking_wait = blocking != 0;
+    return FIGH_OK;
 }
 
 int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes) {

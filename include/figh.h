@@ -51,6 +51,12 @@ int figh_version(void);
 const char *figh_last_error(void);
 int figh_device_count(int *count);
 int figh_device_set(int device);
+/* How the host waits for the device in this process: 0 (default) = the runtime's spinning wait, lowest latency, one busy
+ * CPU per process; 1 = interrupt-driven (hipDeviceScheduleBlockingSync).  For several ranks per node under a CPU quota
+ * (figaroh_plus_amd/dist.py launches): eight spinning ranks plus their runtime threads reach a 16-CPU cgroup quota, and a
+ * process that exhausts it is frozen until the next 100 ms accounting period.  Call before figh_device_set / any
+ * device call.  No reference analogue (the reference has no device). */
+int figh_host_wait_mode(int blocking);
 int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
 int figh_malloc(void **d_ptr, size_t bytes);
 int figh_free(void *d_ptr);
