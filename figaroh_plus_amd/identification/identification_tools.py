@@ -362,17 +362,13 @@ def quadprog_solve_qp(P, q, G=None, h=None, A=None, b=None):
     reference)."""
     from .qp import solve_qp
 
-    qp_G = 0.5 * (P + P.T) + np.eye(P.shape[0]) * (1e-5)  # make sure P is symmetric, pos,def
-    qp_a = -q
-    if A is not None:
-        qp_C = -np.vstack([A, G]).T
-        qp_b = -np.hstack([b, h])
-        meq = A.shape[0]
-    else:  # no equality constraint
-        qp_C = -G.T
-        qp_b = -h
-        meq = 0
-    return solve_qp(qp_G, qp_a, qp_C, qp_b, meq)[0]
+    n = P.shape[0]
+    qp_G = 0.5 * (P + P.T) + 1e-5 * np.eye(n)  # symmetrised and shifted: strictly convex whatever the data
+    eq = A is not None
+    rows = np.vstack([A, G]) if eq else G
+    rhs = np.hstack([b, h]) if eq else h
+    # quadprog's convention is C^T x >= b: both signs flip
+    return solve_qp(qp_G, -q, -rows.T, -rhs, A.shape[0] if eq else 0)[0]
 
 
 def sip_constraints(phi_ref, COM_max, COM_min):
