@@ -157,7 +157,14 @@ def exchange_from_env(prefer="rccl", device_key=None):
     # phase 1
     ok, why = rccl_preflight()
     if device_key is None:
-        device_key = (socket.gethostname(), int(os.environ.get("LOCAL_RANK", rank)))
+        # the device this process actually drives: launchers bind LOCAL_RANK modulo the number of visible devices
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        try:
+            from . import _lib
+            ndev = _lib.device_count()  # hipGetDeviceCount: creates no context
+        except Exception:  # noqa: BLE001
+            ndev = 0
+        device_key = (socket.gethostname(), local % ndev if ndev > 0 else local)
     states = [None] * world
     dist.all_gather_object(states, (bool(ok), why, tuple(device_key)))
     all_ok = all(s[0] for s in states)
@@ -175,5 +182,18 @@ def exchange_from_env(prefer="rccl", device_key=None):
     dist.broadcast_object_list(payload, src=0)
     if payload[0] is None:
         return TorchExchange(), {"collective": "torch.distributed/gloo host-staged (rccl unavailable: %s)" % payload[1][:80]}
-    # phase 3
-    return RcclExchange(world, rank, payload[0]), {"collective": "rccl"}
+    # phase 3: every rank attempts the initialisation and reports; one failure sends all of them to the host-staged
+    # exchange (a rank that fails returns from ncclCommInitRank with an error, it does not leave the others inside it)
+    ex, err = None, ""
+    try:
+        ex = RcclExchange(world, rank, payload[0])
+    except Exception as e:  # noqa: BLE001
+        err = str(e)
+    outcomes = [None] * world
+    dist.all_gather_object(outcomes, (ex is not None, err))
+    if all(o[0] for o in outcomes):
+        return ex, {"collective": "rccl"}
+    if ex is not None:
+        ex.close()
+    reason = next(o[1] for o in outcomes if not o[0])
+    return TorchExchange(), {"collective": "torch.distributed/gloo host-staged (rccl unavailable: %s)" % reason[:80]}

@@ -91,9 +91,25 @@ def _setup_worker(rank, world, port, out_dir, scenario):
         fd.rccl_preflight = lambda: (True, "")
     elif scenario == "shared_device":  # both ranks name the same GPU
         fd.rccl_preflight = lambda: (True, "")
+    elif scenario == "init_fails":     # preflight and id are fine, ncclCommInitRank errors out on one rank
+        fd.rccl_preflight = lambda: (True, "")
+
+        class FakeRccl:
+            closed = False
+
+            def __init__(self, world_, rank_, ident):
+                if rank_ == 1:
+                    raise RuntimeError("simulated: ncclCommInitRank failed on rank 1")
+
+            def close(self):
+                calls["closed"] = calls.get("closed", 0) + 1
+
+        fd.RcclExchange = FakeRccl
 
     def unique_id():
         calls["unique_id"] += 1
+        if scenario == "init_fails":
+            return b"0" * 128
         raise RuntimeError("simulated: ncclGetUniqueId failed")
 
     fd.rccl_unique_id = unique_id
@@ -102,13 +118,13 @@ def _setup_worker(rank, world, port, out_dir, scenario):
     # the fallback exchange must work right away on every rank: no rank is stuck in another collective
     total = ex.allreduce_sum_host(np.array([float(rank + 1)]))
     json.dump({"collective": info["collective"], "kind": type(ex).__name__, "sum": float(total[0]),
-               "unique_id_calls": calls["unique_id"]}, open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+               "unique_id_calls": calls["unique_id"], "closed": calls.get("closed", 0)}, open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
     ex.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("scenario", ["rank1_fails", "id_fails", "shared_device", "no_device"])
+@pytest.mark.parametrize("scenario", ["rank1_fails", "id_fails", "shared_device", "no_device", "init_fails"])
 def test_rccl_setup_is_decided_collectively(tmp_path, scenario):
     """exchange_from_env (the RCCL set-up could deadlock on an asymmetric failure): preflight outcomes are
     all-gathered, every rank takes part in the id broadcast, and all ranks take the same exchange.  Scenarios: the
@@ -129,6 +145,8 @@ def test_rccl_setup_is_decided_collectively(tmp_path, scenario):
         assert "share a device" in res[0]["collective"]
     if scenario == "id_fails":
         assert res[0]["unique_id_calls"] == 1 and res[1]["unique_id_calls"] == 0
+    if scenario == "init_fails":  # the rank whose communicator did come up gives it back
+        assert "rank 1" in res[0]["collective"] and res[0]["closed"] == 1 and res[1]["closed"] == 0
 
 
 def test_shard_range_partitions():

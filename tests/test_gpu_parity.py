@@ -958,3 +958,39 @@ def test_two_process_pipeline_on_one_device(lib, golden_ur10, tmp_path):
         assert np.abs(phi - g["phi_pinv"]).max() <= 1e-6 * np.abs(g["phi_pinv"]).max()
         assert np.abs(np.array(r["col_norm"]) - g["colsq_big"]).max() <= 1e-12 * g["colsq_big"].max()
     assert res[0]["phi_ls"] == res[1]["phi_ls"]  # every rank reduces the same stack: bit-identical results
+
+
+def test_bench_two_ranks_share_the_device(lib):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU a test
+    box has: both ranks drive device 0, so the exchange must be negotiated down to the host-staged one on every rank
+    (the device key is the device actually bound, LOCAL_RANK modulo the device count -- a launch with distinct
+    LOCAL_RANKs on one device used to walk into ncclCommInitRank and fail), the line must be the weak-scaling one with
+    n_gpus = 2 and the step must reproduce the reference's structural result; then the strong-scaling TALOS mode."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    def run(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in [k for k in env if k.startswith("FIGH_")]:
+            del env[k]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900).stdout.decode()
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out[-3000:]
+        return json.loads(lines[0])
+
+    d = run(["--steps", "3", "--warmup", "1", "--samples", "200000"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["samples_total"] == 400000
+    assert d["config"]["ranks"] == 2 and d["config"]["host_wait"] == "block"
+    assert "share a device" in d["config"]["collective"] and d["config"]["result_matches_reference"] is True
+    assert abs(d["value"] - 400000 * 3 / d["config"]["max_rank_seconds"]) <= 1e-6 * d["value"]
+    d = run(["--config", "cfg4", "--steps", "1", "--warmup", "1", "--samples", "200000"])
+    assert d["scaling"] == "strong" and d["config"]["samples_this_rank"] == 100000 and d["config"]["samples_total"] == 200000
+    assert d["config"]["result_matches_reference"] is True
