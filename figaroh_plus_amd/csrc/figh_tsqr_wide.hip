@@ -193,31 +193,33 @@ template <int NRC>
 __device__ __forceinline__ void wy_update_chunk(f64x4 (&B)[NRC], const double *__restrict__ Vl,
                                                 const double *__restrict__ Tl, const f64x4 Rpt,
                                                 double *__restrict__ Rblock, const int lane, const int c, const int g) {
-    // operands of the first two stages: requested together, up front (left to itself the compiler fetches them in pairs
-    // right in front of their MFMAs and the matrix pipe waits ~60 cycles per pair for the LDS round trip)
-    double vc[4 * NRC], tt[4];
-#pragma unroll
-    for (int i = 0; i < 4 * NRC; ++i) vc[i] = Vl[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c];
+    // OPERANDS ARE STREAMED, one row chunk ahead of the MFMAs that use them (four MFMAs = 256 cycles cover the LDS round
+    // trip): the window is 8 + 2 NRC doubles instead of the 8 NRC doubles of "everything up front", and the registers
+    // that frees go into taller tiles -- rows per look-ahead chain are what the kernel's throughput is proportional to.
+    double tt[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) tt[r] = Tl[(g + 4 * r) * kLdt + c];
+    double vc[NRC][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vc[0][r] = Vl[(4 * r + g) * kLdv + c];
     f64x4 G0 = {0.0, 0.0, 0.0, 0.0}, G1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int rc = 0; rc < NRC; ++rc) {
+        if (rc + 1 < NRC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vc[rc + 1][r] = Vl[(16 * (rc + 1) + 4 * r + g) * kLdv + c];
+        }
         // A[i = c][k = g] = V[row 16 rc + 4 r + g][c], B[k = g][j = c] = the tile entry of the same row: K-slice r
-        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 0], B[rc][0], G0, 0, 0, 0);
-        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 1], B[rc][1], G1, 0, 0, 0);
-        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 2], B[rc][2], G0, 0, 0, 0);
-        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[4 * rc + 3], B[rc][3], G1, 0, 0, 0);
+        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[rc][0], B[rc][0], G0, 0, 0, 0);
+        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[rc][1], B[rc][1], G1, 0, 0, 0);
+        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[rc][2], B[rc][2], G0, 0, 0, 0);
+        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[rc][3], B[rc][3], G1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keeps the window: without it every operand is fetched before the first MFMA
     }
-    // (three stages, fenced for the scheduler: hoisting the LDS operands of the last stage into the first costs 32
-    // registers and buys nothing)
-    __builtin_amdgcn_sched_barrier(0);
-    // operands of the last stage (V transposed): in flight while the first stage drains and the T stage runs
+    // operands of the last stage (V transposed), K-slice 0: in flight while the first stage drains and the T stage runs
     double vr[4][NRC];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int rc = 0; rc < NRC; ++rc) vr[s][rc] = Vl[(16 * rc + c) * kLdv + g + 4 * s];
+    for (int rc = 0; rc < NRC; ++rc) vr[0][rc] = Vl[(16 * rc + c) * kLdv + g];
     const f64x4 G = (G0 + G1) + Rpt;  // G[r] = row g + 4 r of R_p,cc + V^T B
     // Wm = T^T G: A[i = c][k = g + 4 r] = T[g + 4 r][c], B[k][j = c] = G[g + 4 r][c]; two accumulators
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
@@ -233,10 +235,16 @@ __device__ __forceinline__ void wy_update_chunk(f64x4 (&B)[NRC], const double *_
     // B -= V Wm: A[i = c][k = g + 4 s] = V[row 16 rc + c][g + 4 s], B[k][j = c] = -Wm[g + 4 s][c]; the NRC row chunks
     // are independent accumulators, so consecutive MFMAs never wait for each other
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
+#pragma unroll
+            for (int rc = 0; rc < NRC; ++rc) vr[s + 1][rc] = Vl[(16 * rc + c) * kLdv + g + 4 * (s + 1)];
+        }
 #pragma unroll
         for (int rc = 0; rc < NRC; ++rc)
             B[rc] = __builtin_amdgcn_mfma_f64_16x16x4f64(vr[s][rc], Wn[s], B[rc], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // WPE = waves per SIMD the kernel is built for (register budget 512 / WPE).
@@ -613,9 +621,11 @@ WyConfig wy_config(const int nc) {
         if (sscanf(e, "%d,%d,%d,%d", &cfg.nw, &cfg.cpw, &cfg.nrc, &cfg.wpe) == 4 && cfg.nw * cfg.cpw >= nch) return cfg;
     }
 #endif
-    if (nch <= 12) return {4, 3, 5, 2};  // 80-row tiles: the rows a look-ahead chain covers are what the throughput is
-                                         // proportional to (64 -> 80 rows: +11 % at n = 191); 247 VGPRs, no spills
-    if (nch <= 16) return {4, 4, 4, 2};
+    // the tallest tile the 256 registers of a wave hold: the rows one look-ahead chain covers are what the throughput is
+    // proportional to (same-box A/B, n = 191: 64 -> 80 -> 96 rows +11 %, +5.5 %; n = 241: 64 -> 80 rows +6 %; the last
+    // step of each costs 8 / 22 spilled registers and still wins)
+    if (nch <= 12) return {4, 3, 6, 2};
+    if (nch <= 16) return {4, 4, 5, 2};
     if (nch <= 24) return {4, 6, 3, 2};
     return {8, 4, 4, 2};
 }
@@ -628,13 +638,15 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
           std::integral_constant<int, NRC_>{}, std::integral_constant<int, WPE_>{});               \
         return true;                                                                               \
     }
-    FIGH_WY_CASE(4, 3, 5, 2)
-    FIGH_WY_CASE(4, 4, 4, 2)
+    FIGH_WY_CASE(4, 3, 6, 2)
+    FIGH_WY_CASE(4, 4, 5, 2)
     FIGH_WY_CASE(4, 6, 3, 2)
     FIGH_WY_CASE(8, 4, 4, 2)
 #ifdef FIGH_ABLATION
     FIGH_WY_CASE(8, 3, 4, 2)
     FIGH_WY_CASE(4, 3, 4, 2)
+    FIGH_WY_CASE(4, 3, 5, 2)
+    FIGH_WY_CASE(4, 4, 4, 2)
     FIGH_WY_CASE(4, 3, 4, 3)
     FIGH_WY_CASE(4, 4, 3, 3)
     FIGH_WY_CASE(4, 3, 3, 3)
