@@ -247,6 +247,60 @@ __device__ __forceinline__ void wy_update_chunk(f64x4 (&B)[NRC], const double *_
     }
 }
 
+// The same update for a chunk that lives in LDS (lch[64 i + lane] = tile entry i of this lane: rows 16 rc + 4 r + g, i =
+// 4 rc + r, column c): one 16-row chunk at a time through eight registers, read twice (V^T B, then B -= V Wm).
+template <int NRC>
+__device__ __forceinline__ void wy_update_lds_chunk(double *__restrict__ lch, const double *__restrict__ Vl,
+                                                    const double *__restrict__ Tl, double *__restrict__ Rblock,
+                                                    const int lane, const int c, const int g) {
+    f64x4 Rpt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rpt[r] = Rblock[lane + 64 * r];
+    double tt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tt[r] = Tl[(g + 4 * r) * kLdt + c];
+    f64x4 G0 = {0.0, 0.0, 0.0, 0.0}, G1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rc = 0; rc < NRC; ++rc) {
+        double vc[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            vc[r] = Vl[(16 * rc + 4 * r + g) * kLdv + c];
+            b[r] = lch[64 * (4 * rc + r) + lane];
+        }
+        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[0], b[0], G0, 0, 0, 0);
+        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[1], b[1], G1, 0, 0, 0);
+        G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[2], b[2], G0, 0, 0, 0);
+        G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[3], b[3], G1, 0, 0, 0);
+    }
+    const f64x4 G = (G0 + G1) + Rpt;
+    const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    f64x4 W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[0], G[0], zero, 0, 0, 0);
+    f64x4 W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[1], G[1], zero, 0, 0, 0);
+    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[2], G[2], W0, 0, 0, 0);
+    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[3], G[3], W1, 0, 0, 0);
+    const f64x4 Wm = W0 + W1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rblock[lane + 64 * r] = Rpt[r] - Wm[r];
+    const f64x4 Wn = -Wm;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rc = 0; rc < NRC; ++rc) {
+        double vr[4];
+        f64x4 b;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            vr[s] = Vl[(16 * rc + c) * kLdv + g + 4 * s];
+            b[s] = lch[64 * (4 * rc + s) + lane];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b = __builtin_amdgcn_mfma_f64_16x16x4f64(vr[s], Wn[s], b, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lch[64 * (4 * rc + s) + lane] = b[s];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // WPE = waves per SIMD the kernel is built for (register budget 512 / WPE).
 //
 // Register queue.  A wave's CPW chunks live in a queue of register slots: F holds the wave's next chunk to become a panel
@@ -256,7 +310,10 @@ __device__ __forceinline__ void wy_update_chunk(f64x4 (&B)[NRC], const double *_
 // the only run-time quantity is `front`.  (The obvious alternative -- fixed slots and a run-time slot index through a
 // switch or a chain of `if (s == sel)` -- makes the compiler route the selected slot through a shared register set
 // (64 v_mov per use) or keep two copies of every slot alive: hundreds of spills, LDS operands fetched one by one.)
-template <int NW, int CPW, int NRC, int WPE>
+// LDSC: chunk NW * CPW -- one more than the register slots hold -- lives in LDS (16 M doubles) and is updated there by its
+// owner until it becomes the last panel.  For column counts one chunk past a register geometry (TALOS: 21 chunks = 4 x 5
+// + 1) this buys the taller tile of the smaller geometry (64 rows with five slots per wave instead of 48 with six).
+template <int NW, int CPW, int NRC, int WPE, bool LDSC>
 __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__restrict__ W, const long rows,
                                                                const long ldw, const int *__restrict__ col_idx,
                                                                const int n, const double *__restrict__ tau,
@@ -268,16 +325,21 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     FIGH_PROF_DECL
     if constexpr (WPE == 1) asm volatile("" ::: "a255");  // the allocation covers the SIMD: never two waves on one
     constexpr int RPL = 4 * NRC, M = 16 * NRC, VBUF = M * kLdv + 16 * kLdt, NQ = CPW - 1;
-    constexpr bool kLateRetire = CPW <= 4;  // see the look-ahead block
+    constexpr bool kLateRetire = CPW <= 4 || LDSC;  // empirical, per geometry (same-box A/B)  // see the look-ahead block
     __shared__ double vt[3][VBUF];      // V (M x kLdv) followed by T (16 x kLdt); three buffers: panel p is still read in
                                         // phase p + 1 (deferred sweep of the wave that factored panel p + 1)
     __shared__ double rpp[NW][256];     // the diagonal block of the panel a wave is factoring (wave-private)
     __shared__ double redbuf[NW][64];   // cross-row-group sums (wave-private)
     __shared__ int fnz[2][NW];
+    __shared__ double lch[LDSC ? 16 * M : 8];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int nch = (nc + 15) >> 4;
+    constexpr int LC = NW * CPW;                               // the chunk that lives in LDS (LDSC)
+    const int nreg = LDSC ? (nch < LC ? nch : LC) : nch;       // chunks held in register slots
+    const bool lhave = LDSC && nch > LC;                       // the matrix reaches into the LDS chunk
+    const bool lowner = lhave && wave == (LC & (NW - 1));      // the wave that looks after it
 #ifdef FIGH_ABLATION
     // FIGH_WY_RALIAS: the workgroups of an XCD share ONE triangle (garbage results, same instruction stream): what the
     // kernel would cost if the R blocks came from L2 instead of HBM / MALL
@@ -290,10 +352,16 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     double *red = redbuf[wave];
 
     // this wave's columns of the triangle start empty
+    if (lowner)
+        for (int p = 0; p <= LC; ++p) {
+            double *b = block(p, LC);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[lane + 64 * r] = 0.0;
+        }
 #pragma unroll
     for (int s = 0; s < CPW; ++s) {
         const int cc = wave + NW * s;
-        if (cc < nch)
+        if (cc < nreg)
             for (int p = 0; p <= cc; ++p) {
                 double *b = block(p, cc);
 #pragma unroll
@@ -325,6 +393,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     init_slot(F, 0);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) init_slot(Q[j], j + 1);
+
     const unsigned toff = 8u * (unsigned)g;
     const unsigned ldw8 = 8u * (unsigned)ldw;  // bytes per row (the host side guarantees 64 * ldw * 8 < 2^32)
 
@@ -393,12 +462,29 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
             for (int j = 0; j < NQ; ++j) FIGH_WY_LOAD(Q[j], r0);
         }
         prefetched = next_full;
+        // The LDS chunk is requested at the top of the tile (its LDS home is in use until the tile's last panel) into a
+        // record that only lives until the data are in LDS, a few lines further down.
+        // Its column source is re-derived here every tile (one index load) rather than held in registers across the tile.
+        Slot L;
+        {
+            int lc_ = c;
+            asm volatile("" : "+v"(lc_));  // opaque: not to be hoisted out of the tile loop
+            const int lcol = 16 * LC + lc_;
+            L.wlive = lowner && lcol < n;
+            L.tlive = lowner && lcol == n && tau != nullptr;
+            L.wcol = L.wlive ? (col_idx ? col_idx[lcol] : lcol) : 0;
+            L.boff = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)L.wcol);
+        }
+#pragma unroll
+        for (int rc = 0; rc < NRC; ++rc) L.t[rc] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (lowner) FIGH_WY_LOAD(L, r0);
         if (blkw) {  // row-block weights (WLS): row r is scaled by blkw[r / rows_per_blk]
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const long row = r0 + 16 * (i >> 2) + 4 * (i & 3) + g;
                 const double scale = blkw[(row < rows ? row : rows - 1) / rows_per_blk];
                 F.t[i >> 2][i & 3] *= scale;
+                if (lowner) L.t[i >> 2][i & 3] *= scale;
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) Q[j].t[i >> 2][i & 3] *= scale;
             }
@@ -406,6 +492,17 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         // the first column with a non-zero in this tile: the column steps in front of it are identities (stacked
         // triangles in the merge levels, the joint-torque rows of a tree)
         int myfirst = 16 * nch;
+        if (lowner) {
+            bool nz = false;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                nz |= (L.t[i >> 2][i & 3] != 0.0);
+                lch[64 * i + lane] = L.t[i >> 2][i & 3];
+            }
+            const unsigned long long b = __ballot(nz);
+            const unsigned m16 = (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);
+            if (m16) myfirst = 16 * LC + __ffs((int)m16) - 1;
+        }
 #pragma unroll
         for (int s = CPW - 1; s >= 0; --s) {
             bool nz = false;
@@ -440,8 +537,16 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = bpp[lane + 64 * r];
                 double X[RPL];
+                const bool from_lds = LDSC && p0 == LC;
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) X[i] = F.t[i >> 2][i & 3];
+                if constexpr (LDSC) {
+                    if (from_lds) {
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i) X[i] = lch[64 * i + lane];
+                    }
+                }
                 FIGH_WY_WAVE_SYNC();
                 FIGH_PROF_ADD(8);
                 wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
@@ -449,13 +554,15 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                 FIGH_PROF_ADD(9);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bpp[lane + 64 * r] = Rl[lane + 64 * r];
-                if constexpr (!kLateRetire) FIGH_WY_RETIRE(rn);
+                if constexpr (!kLateRetire) {
+                    if (!(LDSC && p0 == LC)) FIGH_WY_RETIRE(rn);  // (the LDS chunk has no register slot to rotate)
+                }
                 __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
             FIGH_PROF_ADD(2);
             if constexpr (kLateRetire) {
-                if (wave == (p0 & (NW - 1))) {
+                if (wave == (p0 & (NW - 1)) && !(LDSC && p0 == LC)) {
                     FIGH_WY_RETIRE(rn);
                     FIGH_PROF_ADD(10);
                 }
@@ -495,7 +602,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
 #pragma unroll
                         for (int r = 0; r < 4; ++r) rp[r] = b1[lane + 64 * r];
                     }
-                    wy_update_chunk<NRC>(F.t, Vl, Tl, rp, block(p, pn), lane, c, g);
+                    const bool from_lds = LDSC && pn == LC;
+                    if (from_lds) wy_update_lds_chunk<NRC>(lch, Vl, Tl, block(p, pn), lane, c, g);
+                    else wy_update_chunk<NRC>(F.t, Vl, Tl, rp, block(p, pn), lane, c, g);
                     FIGH_PROF_ADD(3);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Rl[lane + 64 * r] = rq[r];
@@ -503,6 +612,13 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     double X[RPL];
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) X[i] = F.t[i >> 2][i & 3];
+                    if constexpr (LDSC) {
+                        if (from_lds) {  // (a real branch: as a select the sixteen LDS reads were issued for every panel)
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int i = 0; i < RPL; ++i) X[i] = lch[64 * i + lane];
+                        }
+                    }
                     FIGH_WY_WAVE_SYNC();
                     FIGH_PROF_ADD(7);
                     wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
@@ -514,7 +630,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     // wave after the barrier, where nobody waits for them (same-box A/B: n = 191 +4 %); with six slots
                     // the rotation is long and last phase's owner, who has two sweeps to do, is the critical wave
                     // (TALOS -3 %), so there it stays in front of the barrier
-                    if constexpr (!kLateRetire) FIGH_WY_RETIRE(rn);
+                    if constexpr (!kLateRetire) {
+                        if (!from_lds) FIGH_WY_RETIRE(rn);
+                    }
                     __builtin_amdgcn_s_setprio(0);
                     // LOAD BALANCE: the look-ahead (chunk update + 16 dependent column steps) is about two trailing
                     // sweeps long, so this wave leaves panel p to its other chunks for the next phase, when it is not
@@ -531,7 +649,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     const int pp = rep == 0 ? p - 1 : p;  // the panel applied in this sweep, to the chunks behind pp + 1
                     const double *Vx = rep == 0 ? vt[vbp] : Vl;
                     const double *Tx = Vx + M * kLdv;
-                    if (front > pp + 1 && front < nch) {
+                    if (front > pp + 1 && front < nreg) {
                         double *b = block(pp, front);
                         f64x4 rb;
 #pragma unroll
@@ -542,7 +660,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) {
                         const int cc = front + NW * (j + 1);
-                        if (cc > pp + 1 && cc < nch) {
+                        if (cc > pp + 1 && cc < nreg) {
                             double *b = block(pp, cc);
                             f64x4 rb;
 #pragma unroll
@@ -551,13 +669,21 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if constexpr (LDSC) {
+                        // The LDS chunk is updated by a different wave every phase -- any wave can, it is in shared
+                        // memory -- namely one that has a single sweep to do: wave pp + 2 is neither the owner of panel
+                        // pp + 1 nor the wave that owes a deferred sweep (owner of panel pp), so this never runs in the
+                        // deferred round either.  Consecutive panels are separated by the phase barrier.
+                        if (lhave && wave == ((pp + 2) & (NW - 1)) && LC > pp + 1)
+                            wy_update_lds_chunk<NRC>(lch, Vx, Tx, block(pp, LC), lane, c, g);
+                    }
                 }
                 if (owe) deferred = false;
                 FIGH_PROF_ADD(5);
                 __syncthreads();
                 FIGH_PROF_ADD(6);
                 if constexpr (kLateRetire) {
-                    if (is_owner) {
+                    if (is_owner && !(LDSC && pn == LC)) {
                         FIGH_WY_RETIRE(rn);
                         FIGH_PROF_ADD(11);
                     }
@@ -578,8 +704,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     // ---- write this wave's columns of the nc x nc row-major triangle (zeros below the diagonal)
     double *Ro = Rout + (long)blockIdx.x * nc * nc;
 #pragma unroll
-    for (int s = 0; s < CPW; ++s) {
-        const int cc = wave + NW * s;
+    for (int s = 0; s < CPW + (LDSC ? 1 : 0); ++s) {
+        const int cc = s < CPW ? wave + NW * s : LC;  // (the extra round: the LDS chunk's columns, by its owner)
+        if (s == CPW && !lowner) continue;
         if (cc >= nch) continue;
         const int col = 16 * cc + c;
         for (int pb = 0; pb < nch; ++pb) {
@@ -594,12 +721,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     }
 }
 
-template <int NW, int CPW, int NRC, int WPE>
+template <int NW, int CPW, int NRC, int WPE, bool LDSC>
 int wy_occupancy() {  // resident workgroups per CU (registers and LDS decide)
     static int nb = 0;
     if (!nb) {
         int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, tsqr_wy_kernel<NW, CPW, NRC, WPE>, 64 * NW, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, tsqr_wy_kernel<NW, CPW, NRC, WPE, LDSC>, 64 * NW, 0) != hipSuccess ||
             v < 1)
             v = 1;
         nb = v;
@@ -608,7 +735,7 @@ int wy_occupancy() {  // resident workgroups per CU (registers and LDS decide)
 }
 
 struct WyConfig {
-    int nw, cpw, nrc, wpe;
+    int nw, cpw, nrc, wpe, ldsc;
 };
 
 // Geometry by column count (one wave per SIMD throughout, see tsqr_wy_kernel): as few waves per workgroup -- as many
@@ -617,29 +744,36 @@ WyConfig wy_config(const int nc) {
     const int nch = (nc + 15) >> 4;
 #ifdef FIGH_ABLATION
     if (const char *e = getenv("FIGH_WY_CFG")) {  // "nw,cpw,nrc,wpe" (ablation build only)
-        WyConfig cfg{0, 0, 0, 0};
-        if (sscanf(e, "%d,%d,%d,%d", &cfg.nw, &cfg.cpw, &cfg.nrc, &cfg.wpe) == 4 && cfg.nw * cfg.cpw >= nch) return cfg;
+        WyConfig cfg{0, 0, 0, 0, 0};  // a fifth number 1 selects the LDS-chunk form (one chunk beyond the register slots)
+        const int got = sscanf(e, "%d,%d,%d,%d,%d", &cfg.nw, &cfg.cpw, &cfg.nrc, &cfg.wpe, &cfg.ldsc);
+        if (got >= 4 && cfg.nw * cfg.cpw + (cfg.ldsc ? 1 : 0) >= nch) return cfg;
     }
 #endif
     // the tallest tile the 256 registers of a wave hold: the rows one look-ahead chain covers are what the throughput is
     // proportional to (same-box A/B, n = 191: 64 -> 80 -> 96 rows +11 %, +5.5 %; n = 241: 64 -> 80 rows +6 %; the last
     // step of each costs 8 / 22 spilled registers and still wins)
-    if (nch <= 12) return {4, 3, 6, 2};
-    if (nch <= 16) return {4, 4, 5, 2};
-    if (nch <= 24) return {4, 6, 3, 2};
-    return {8, 4, 4, 2};
+    if (nch <= 12) return {4, 3, 6, 2, 0};
+    if (nch <= 16) return {4, 4, 5, 2, 0};
+    if (nch <= 20) return {4, 5, 4, 2, 0};
+    if (nch == 21) return {4, 5, 4, 2, 1};  // TALOS (331 columns): 64-row tiles, chunk 20 in LDS
+    if (nch <= 24) return {4, 6, 3, 2, 0};
+    return {8, 4, 4, 2, 0};
 }
 
 template <class F>
 bool wy_dispatch(const WyConfig cfg, F &&f) {
-#define FIGH_WY_CASE(NW_, CPW_, NRC_, WPE_)                                                        \
-    if (cfg.nw == NW_ && cfg.cpw == CPW_ && cfg.nrc == NRC_ && cfg.wpe == WPE_) {                  \
+#define FIGH_WY_CASE_L(NW_, CPW_, NRC_, WPE_, L_)                                                  \
+    if (cfg.nw == NW_ && cfg.cpw == CPW_ && cfg.nrc == NRC_ && cfg.wpe == WPE_ && (cfg.ldsc != 0) == L_) { \
         f(std::integral_constant<int, NW_>{}, std::integral_constant<int, CPW_>{},                 \
-          std::integral_constant<int, NRC_>{}, std::integral_constant<int, WPE_>{});               \
+          std::integral_constant<int, NRC_>{}, std::integral_constant<int, WPE_>{},                \
+          std::integral_constant<bool, L_>{});                                                     \
         return true;                                                                               \
     }
+#define FIGH_WY_CASE(NW_, CPW_, NRC_, WPE_) FIGH_WY_CASE_L(NW_, CPW_, NRC_, WPE_, false)
     FIGH_WY_CASE(4, 3, 6, 2)
     FIGH_WY_CASE(4, 4, 5, 2)
+    FIGH_WY_CASE(4, 5, 4, 2)
+    FIGH_WY_CASE_L(4, 5, 4, 2, true)
     FIGH_WY_CASE(4, 6, 3, 2)
     FIGH_WY_CASE(8, 4, 4, 2)
 #ifdef FIGH_ABLATION
@@ -660,6 +794,7 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
     FIGH_WY_CASE(8, 4, 2, 3)
 #endif
 #undef FIGH_WY_CASE
+#undef FIGH_WY_CASE_L
     return false;
 }
 
@@ -668,8 +803,9 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
 // persistent workgroups the wide kernel wants for nc columns (one private triangle each)
 long tsqr_wide_workgroups(const int nc, const int cus) {
     int occ = 1;
-    wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE) {
-        occ = wy_occupancy<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value, decltype(WPE)::value>();
+    wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
+        occ = wy_occupancy<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value, decltype(WPE)::value,
+                           decltype(LDSC)::value>();
     });
     return (long)cus * occ;
 }
@@ -696,8 +832,9 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
         if (!prof) return FIGH_ERR_ALLOC;
     }
 #endif
-    const bool ok = wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE) {
-        hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value, decltype(WPE)::value>),
+    const bool ok = wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
+        hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
+                                           decltype(WPE)::value, decltype(LDSC)::value>),
                            dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, stream(), W, rows, ldw, col_idx, n, tau,
                            d_blkw, rows_per_blk, Rblk, Rws_out, nc, prof);
     });
