@@ -303,11 +303,11 @@ def main():
                 pmc = json.load(f)
             src = "profiles/r02_pmc_summary_cfg4.json: a committed rocprofv3 --pmc run of this command, NOT measured in this run"
             for key, kname in (("regressor_tree", "regressor_tape_kernel<16, true, true, true, true>"),
-                               ("tsqr", "tsqr_wy_kernel<4, 6, 3, 2>")):
+                               ("tsqr", "tsqr_wy_kernel<4, 5, 4, 2, true>")):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
                     roof[key]["traffic_source"] = src
-            k = pmc.get("tsqr_wy_kernel<4, 6, 3, 2>", {})
+            k = pmc.get("tsqr_wy_kernel<4, 5, 4, 2, true>", {})
             if "tsqr" in roof and "SQ_INSTS_VALU_MFMA_MOPS_F64" in k:
                 # one MOPS unit = 512 flops (4 units per v_mfma_f64_16x16x4 = 2048 flops, checked against SQ_INSTS_MFMA)
                 roof["tsqr"]["executed_mfma_flops_per_launch"] = 512.0 * k["SQ_INSTS_VALU_MFMA_MOPS_F64"]
