@@ -581,10 +581,12 @@ def test_tx40_real_data_known_answers_hip(lib):
     assert (np.abs(std_w - z["std_wls"])[ok] / z["std_wls"][ok]).max() <= 2e-3
 
 
-@pytest.mark.parametrize("n", [1, 15, 16, 17, 49, 63, 64, 65, 79, 80, 81, 128, 200, 257, 384, 400, 511])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 49, 63, 64, 65, 79, 80, 81, 128, 193, 200, 257, 272, 305, 320, 330, 336, 384, 400,
+                               511])
 @pytest.mark.parametrize("rows", [1, 63, 64, 65, 1000, 20011])
 def test_tsqr_shapes_against_lapack(lib, n, rows):
-    """Every kernel family / boundary of figh_tsqr (1 wave, tsqr2 4 and 5 chunks, column-split workgroups) on
+    """Every kernel family / boundary of figh_tsqr (1 wave, tsqr2 4 and 5 chunks, every geometry of the blocked kernel
+    incl. the two with a chunk in LDS: 321-336 and 385-400 columns with the tau column) on
     random full-rank matrices: R^T R = A^T A, |diag R| equals LAPACK's when rows >= n; tau column; row weights."""
     from figaroh_plus_amd.tools.qrdecomposition import rfactor
     rng = np.random.default_rng(1000 * n + rows)
