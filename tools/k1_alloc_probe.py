@@ -13,13 +13,18 @@ mode, flags, ft = regressor_flags(meta['param'], False); dm = robot.device_model
 dq, dv, da = (_lib.DeviceArray.from_host(x.reshape(-1)) for x in (q, v, a))
 dc = _lib.DeviceArray((84,))
 junk = []
-for trial in range(8):
+for trial in range(12):
     W = _lib.DeviceArray((6 * N * 84,))
     for _ in range(3): _lib.regressor_build(dm, mode, flags, ft, N, dq, dv, da, W, 84, dc)
     _lib.synchronize(); t0 = time.perf_counter()
     for _ in range(10): _lib.regressor_build(dm, mode, flags, ft, N, dq, dv, da, W, 84, dc)
     _lib.synchronize(); dt = (time.perf_counter() - t0) / 10
-    print("trial %d  W at 0x%x (mod 2MB %d, mod 1GB %d MB)  K1 %.3f ms" % (trial, W.ptr, W.ptr % (2 << 20), (W.ptr % (1 << 30)) >> 20, dt * 1e3), flush=True)
+    lib = _lib.load()
+    for _ in range(2): _lib.check(lib.figh_memset(W.ptr, 0, W.nbytes))
+    _lib.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): _lib.check(lib.figh_memset(W.ptr, 0, W.nbytes))
+    _lib.synchronize(); dm_ = (time.perf_counter() - t0) / 10
+    print("trial %d  W at 0x%x (mod 2MB %d, mod 1GB %d MB)  K1 %.3f ms  memset %.3f ms" % (trial, W.ptr, W.ptr % (2 << 20), (W.ptr % (1 << 30)) >> 20, dt * 1e3, dm_ * 1e3), flush=True)
     if trial % 2 == 0:
         junk.append(_lib.DeviceArray((1 << 20) * (trial + 3),))  # perturb the next placement
     W.free()
