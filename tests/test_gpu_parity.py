@@ -996,3 +996,15 @@ def test_bench_two_ranks_share_the_device(lib):
     d = run(["--config", "cfg4", "--steps", "1", "--warmup", "1", "--samples", "200000"])
     assert d["scaling"] == "strong" and d["config"]["samples_this_rank"] == 100000 and d["config"]["samples_total"] == 200000
     assert d["config"]["result_matches_reference"] is True
+
+
+def test_tsqr_randomised_stress(lib):
+    """tools/tsqr_stress.py: 60 random cases over the blocked-kernel range (column counts on and off the geometry
+    boundaries, ragged and short row counts, column gathers, tau, row-block weights, zero leading blocks, exactly
+    dependent columns whose pivots must come out at rounding level) -- run as a child process with a fixed seed."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tsqr_stress.py"), "60", "20250410"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and b"all 60 cases ok" in out.stdout, out.stdout.decode()[-2000:]
