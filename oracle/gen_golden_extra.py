@@ -28,7 +28,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def qr_pivoting_fixture():
     out = {}
-    for cfg, mname in (("cfg2_ur10", "ur10"), ("cfg1_tx40", "tx40")):
+    for cfg, mname in (("cfg2_ur10", "ur10"), ("cfg1_tx40", "tx40"), ("cfg3_tiago", "tiago"), ("cfg4_talos", "talos"),
+                       ("cfg5_human", "human")):
         meta = json.load(open(os.path.join(GOLD, cfg + ".json")))
         z = np.load(os.path.join(GOLD, cfg + ".npz"))
         flat = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", mname + ".json")).to_flat()
