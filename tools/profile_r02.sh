@@ -7,7 +7,7 @@ O=gpurun_out/r02; mkdir -p $O
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_INSTS_VALU_MFMA[A-Z0-9_]*\|SQ_VALU_MFMA_BUSY_CYCLES\|SQ_INSTS_MFMA\|SQ_BUSY_CYCLES\|SQ_INSTS_VALU\b" | sort -u > $O/avail_counters.txt
 prof() { # name, extra rocprof args..., -- command
   local name=$1; shift
-  rocprofv3 --kernel-trace "$@" > $O/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace "$@" > $O/$name.log 2>&1  # (bounded: a counter pass that dies can hang in finalisation)
 }
 B2="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 B4="python3 bench.py --config cfg4 --steps 3 --warmup 1"
@@ -24,6 +24,15 @@ prof cfg4_mfma --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ
 prof cfg4_mfma2 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES -d $O/cfg4_mfma2 -o r -- $B4
 prof cfg3_stats --stats -d $O/cfg3_stats -o r -- $B3;  grep '^{' $O/cfg3_stats.log | tail -1 > $O/r02_cfg3_bench_under_rocprof.json
 prof cfg5_stats --stats -d $O/cfg5_stats -o r -- $B5;  grep '^{' $O/cfg5_stats.log | tail -1 > $O/r02_cfg5_bench_under_rocprof.json
+# MFMA / traffic counters for the TIAGo and human shapes as well (one pass each)
+prof cfg3_mfma --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/cfg3_mfma -o r -- $B3
+prof cfg3_fetch --pmc FETCH_SIZE -d $O/cfg3_fetch -o r -- $B3   # (FETCH_SIZE and WRITE_SIZE never in one pass: that
+prof cfg3_write --pmc WRITE_SIZE -d $O/cfg3_write -o r -- $B3   #  combination aborted the profiler and cost 40 GPU-minutes)
+prof cfg5_mfma --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/cfg5_mfma -o r -- $B5
+prof cfg5_fetch --pmc FETCH_SIZE -d $O/cfg5_fetch -o r -- $B5
+prof cfg5_write --pmc WRITE_SIZE -d $O/cfg5_write -o r -- $B5
+python3 tools/pmc_summary.py $O/r02_pmc_summary_cfg3.json $O/cfg3_mfma/r_results.db $O/cfg3_fetch/r_results.db $O/cfg3_write/r_results.db > $O/r02_pmc_cfg3.txt 2>&1
+python3 tools/pmc_summary.py $O/r02_pmc_summary_cfg5.json $O/cfg5_mfma/r_results.db $O/cfg5_fetch/r_results.db $O/cfg5_write/r_results.db > $O/r02_pmc_cfg5.txt 2>&1
 for c in cfg2 cfg3 cfg4 cfg5; do
   python3 tools/rocpd_summary.py $O/${c}_stats/r_results.db > $O/r02_${c}_kernel_stats.txt 2>&1
 done
