@@ -7,7 +7,7 @@ O=gpurun_out/r02; mkdir -p $O
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_INSTS_VALU_MFMA[A-Z0-9_]*\|SQ_VALU_MFMA_BUSY_CYCLES\|SQ_INSTS_MFMA\|SQ_BUSY_CYCLES\|SQ_INSTS_VALU\b" | sort -u > $O/avail_counters.txt
 prof() { # name, extra rocprof args..., -- command
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace "$@" > $O/$name.log 2>&1  # (bounded: a counter pass that dies can hang in finalisation)
+  timeout -k 10 300 rocprofv3 --kernel-trace "$@" > $O/$name.log 2>&1  # (bounded: a counter pass that dies can hang in finalisation)
 }
 B2="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 B4="python3 bench.py --config cfg4 --steps 3 --warmup 1"
