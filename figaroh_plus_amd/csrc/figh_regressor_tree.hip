@@ -64,6 +64,10 @@ struct TapeOp {
 
 namespace {
 
+#ifdef FIGH_ABLATION
+__device__ int g_tree_hotin = 0;
+#endif
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Stream one link segment -- the tile, 64 rows x LS doubles -- to rows rowbase .. + nvalid - 1, columns col0 .. col0 + LS - 1
@@ -181,7 +185,14 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
         const long i0 = t * 64;
         const int nvalid = (int)((N - i0) < 64 ? (N - i0) : 64);
         const long i = i0 + (lane < nvalid ? lane : nvalid - 1);
+#ifdef FIGH_ABLATION
+        // FIGH_TREE_HOTIN: every tile reads the inputs of the first 64 samples (wrong numbers, same instruction stream):
+        // what the kernel would cost if q, v, a came from cache (tools/tree_hotin.sh)
+        const long iin = g_tree_hotin ? (lane < nvalid ? lane : nvalid - 1) : i;
+        const double *qi = q + iin * nq, *vi = v + iin * nv, *ai = a + iin * nv;
+#else
         const double *qi = q + i * nq, *vi = v + i * nv, *ai = a + i * nv;
+#endif
         // state of the current link
         double V[6] = {0, 0, 0, 0, 0, 0}, A[6] = {-g0, -g1, -g2, 0, 0, 0};
         double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};  // EXTFF: link -> root-joint frame
@@ -627,6 +638,10 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     if (it == g_tapes.end()) {
         std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls) : build_tape_rows(h, mode, flags, ft_mask, ls);
 #ifdef FIGH_ABLATION
+        {
+            const int hot = getenv("FIGH_TREE_HOTIN") != nullptr;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tree_hotin), &hot, sizeof(int));
+        }
         if (const char *e = getenv("FIGH_TREE_TAPE")) {  // store-pattern ceilings: W is all zeros, timing only
             TapeBuilder T(h);
             const int nrows = mode == FIGH_MODE_EXT_WRENCH ? 6 : h.nv;
