@@ -29,3 +29,16 @@ def single_threaded_blas(n=0):
     if not _blas_controller:
         return _NoLimit()
     return _blas_controller.limit(limits=1, user_api="blas")
+
+
+def host_tail(fn):
+    """Decorator for the drop-in functions whose host part is small dense algebra on n x n triangles (inverse, SVD, pivoted
+    QR, QP): that part runs with BLAS / LAPACK on one thread (see single_threaded_blas); the device work is unaffected."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with single_threaded_blas():
+            return fn(*args, **kwargs)
+
+    return wrapper

@@ -10,6 +10,7 @@ import operator
 import numpy as np
 
 from .. import _lib
+from .._host import host_tail
 from ..device import to_device, vector_to_device
 from ..tools.qrdecomposition import rfactor
 
@@ -77,6 +78,7 @@ def _triangle_with_tau(W_b, tau, block_weight=None):
     return Raug[:r, :r], Raug[:r, r], Raug[r, r]
 
 
+@host_tail
 def least_squares(W_b, tau):
     """OLS solution of ``W_b phi = tau`` -- replaces ``np.linalg.pinv(W_base) @ tau``
     (examples/ur10/identification.py:159, examples/human/identification.py:467) and
@@ -85,6 +87,7 @@ def least_squares(W_b, tau):
     return np.linalg.solve(R, z)
 
 
+@host_tail
 def relative_stdev(W_b, phi_b, tau):
     """Relative standard deviation (%) of the identified parameters (identification_tools.py:204-234).
 
@@ -127,6 +130,7 @@ def block_residual_sqnorms(tau_meas, tau_est, nblocks):
     return np.array(res)
 
 
+@host_tail
 def weigthed_least_squares(robot, phi_b, W_b, tau_meas, tau_est, param):
     """Library WLS (identification_tools.py:291-331), including its conventions: per-joint
     ``sigma_j = ||tau_j - tau_est_j|| / (n_j - len(phi_b))`` (a norm, not a variance), rows scaled by
@@ -147,6 +151,7 @@ def weigthed_least_squares(robot, phi_b, W_b, tau_meas, tau_est, param):
     return np.around(np.linalg.solve(R, z), 6)
 
 
+@host_tail
 def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks):
     """Script WLS of examples/staubli_TX40/identification.py:305-346.  ``nblocks``: number of equal joint blocks or
     the list of block lengths.  sigma_j^2 = ||tau_j - W_j phi_b||^2 / n_j, phi = (W^T S^-1 W)^-1 W^T S^-1 tau
@@ -328,6 +333,7 @@ def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
     return W_list, tau_list
 
 
+@host_tail
 def sip_qp_terms(robot, q, v, a, tau, param, col_idx, phi_ref, alpha, coupling=False):
     """The data terms of ``calculate_standard_parameters`` (identification_tools.py:466-572, the SIP quadratic
     program): ``P = (1-alpha) sf1 I + alpha sf2 W^T W`` and ``r = -((1-alpha) sf1 phi_ref + alpha sf2 W^T tau)`` with
@@ -392,6 +398,7 @@ def sip_constraints(phi_ref, COM_max, COM_min):
     return G, h
 
 
+@host_tail
 def calculate_standard_parameters(model, W, tau, COM_max, COM_min, params_standard_u, alpha):
     """(phi_standard, phi_ref) -- identification_tools.py:466-572: the standard inertial parameters that fit the
     measurements (weight alpha), stay near the URDF values (weight 1 - alpha) and keep first moments, masses and

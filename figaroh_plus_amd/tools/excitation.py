@@ -15,6 +15,7 @@ trajectories, and the r x r SVD runs on the host.
 import numpy as np
 
 from .. import _lib
+from .._host import host_tail
 from .regressor import _samples_to_device, regressor_flags
 
 
@@ -47,6 +48,7 @@ def base_regressor_triangle(robot, q, v, a, param, idx_e, idx_base, R_stack=None
     return np.triu(d_R.to_host().reshape(r, r))
 
 
+@host_tail
 def objective_cond(robot, q, v, a, param, idx_e, idx_base, R_stack=None, coupling=False):
     """np.linalg.cond(W_b) of the reference's ``objective_func`` (2-norm condition number)."""
     R = base_regressor_triangle(robot, q, v, a, param, idx_e, idx_base, R_stack, coupling)

@@ -12,6 +12,7 @@ and the expression strings follow the reference statement by statement.
 import numpy as np
 
 from .. import _lib
+from .._host import host_tail
 from .._host import single_threaded_blas
 from ..device import GpuMatrix, index_to_device, to_device, vector_to_device
 
@@ -76,6 +77,7 @@ def _base_columns(Wd, idx, keep_on_device=False):
     return out if keep_on_device else out.numpy()
 
 
+@host_tail
 def get_baseIndex(W_e, params_r, tol_qr=TOL_QR):
     """Indices of the linearly independent columns (qrdecomposition.py:274-296)."""
     R = rfactor(W_e)
@@ -89,6 +91,7 @@ def build_baseRegressor(W_e, idx_base):
     return _base_columns(Wd, list(idx_base), on_dev)
 
 
+@host_tail
 def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
     """(W_b, params_base, idx_base) -- qrdecomposition.py:190-271."""
     Wd, on_dev = to_device(W_e)
@@ -103,6 +106,7 @@ def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
     return W_b, params_base, idx_base
 
 
+@host_tail
 def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR):
     """(W_b, base_parameters, params_base, phi_b[, phi_std]) -- qrdecomposition.py:89-187."""
     Wd, on_dev = to_device(W_e)
@@ -132,6 +136,7 @@ def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR):
     return W_b, base_parameters, params_base, phi_b
 
 
+@host_tail
 def QR_pivoting(tau, W_e, params_r, tol_qr=TOL_QR):
     """(W_b, base_parameters) with column pivoting -- qrdecomposition.py:24-86.
 
@@ -162,6 +167,7 @@ def QR_pivoting(tau, W_e, params_r, tol_qr=TOL_QR):
     return W_b, dict(zip(params_base, phi_b))
 
 
+@host_tail
 def cond_num(W_b, norm_type=None):
     """Condition number of the base regressor (qrdecomposition.py:316-332) from the singular values of
     its TSQR triangle (identical to those of ``W_b``)."""

@@ -8,6 +8,7 @@ stacked regressor, no CPU fallback).  ``W`` arguments may be NumPy arrays or
 import numpy as np
 
 from .. import _lib
+from .._host import host_tail
 from ..device import GpuMatrix, index_to_device, to_device
 
 FT_BITS = {"Fx": 0, "Fy": 1, "Fz": 2, "Mx": 3, "My": 4, "Mz": 5}
@@ -204,6 +205,7 @@ def _total_regressor(W_b_u, W_b_l, W_l, meas_u, meas_l, nblocks, n_u, n_l, W_e_l
     return (Wt if on_dev else Wt.numpy()), V_norm, residue
 
 
+@host_tail
 def build_total_regressor_current(W_b_u, W_b_l, W_l, I_u, I_l, param_standard_l, param):
     """(W_tot, V_norm, residue) -- regressor.py:296-412: unloaded and loaded base regressors stacked, the joint currents
     as block-diagonal columns (one drive gain per joint), the loaded link's inertial columns and its mass column; the
@@ -230,6 +232,7 @@ def build_total_regressor_current(W_b_u, W_b_l, W_l, I_u, I_l, param_standard_l,
     return _total_regressor(Wu, Wl, Wf, I_u, I_l, nb_joints, n_samples, n_samples, W_e_l, body * stride + 9, param, on_dev)
 
 
+@host_tail
 def build_total_regressor_wrench(W_b_u, W_b_l, W_l, tau_u, tau_l, param_standard_l, param):
     """(W_tot, V_norm, residue) -- regressor.py:415-500: the external-wrench variant (six wrench components instead of
     joints, no column elimination on the payload block)."""
