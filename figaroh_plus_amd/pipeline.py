@@ -194,6 +194,7 @@ class IdentificationPipeline:
         mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
         handle = self.robot.device_model()
         if self.W is None:  # HBM buffers are allocated once and reused by every step
+            self._kept_cache = None
             rows_per_sample, ncols = handle.shape(mode, flags)
             # W stays in HBM.  Chains: the reference's dense layout (the chain kernel streams one contiguous run per tile).
             # Trees: the link-padded layout of figh_regressor_build_padded -- 16 columns per link, every (row, link)
@@ -220,18 +221,26 @@ class IdentificationPipeline:
             _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         col_norm = ex.sum_columns(d_colsq, W.ref_cols)
         small = col_norm < self.tol_e  # regressor.py:271-277 (NaN compares False: kept, as in the reference's loop)
-        idx_e = np.flatnonzero(small).tolist()
-        kept_i32 = np.flatnonzero(~small).astype(np.int32)
-        kept = kept_i32.tolist()
-        params_r = [self.names[i] for i in kept]
-        n = len(kept)
+        d_R, d_idx = self._d_R, self._d_idx
+        cached = getattr(self, "_kept_cache", None)
+        if cached is not None and np.array_equal(cached[0], small):
+            # the same columns as in the previous pass: the lists derived from the mask and the column list that is
+            # already in HBM are reused (the decision itself is taken afresh from this pass's norms every time)
+            _, idx_e, params_r, n, hint = cached
+            idx_e, params_r = list(idx_e), list(params_r)  # (the caller owns what run() returns)
+        else:
+            idx_e = np.flatnonzero(small).tolist()
+            kept_i32 = np.flatnonzero(~small).astype(np.int32)
+            params_r = [self.names[i] for i in kept_i32.tolist()]
+            n = len(params_r)
+            dev_cols = (kept_i32 // 14) * 16 + kept_i32 % 14 if self._padded else kept_i32  # W's own column numbering
+            _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, dev_cols.ctypes.data, dev_cols.nbytes))
+            hint = self._structure_hint(mode, kept_i32)
+            self._kept_cache = (small.copy(), list(idx_e), list(params_r), n, hint)
         # K3: TSQR over the kept columns (+ tau), then the cross-rank stack
         with_tau = self.d_tau is not None
         nc = n + (1 if with_tau else 0)
-        d_R, d_idx = self._d_R, self._d_idx
-        dev_cols = (kept_i32 // 14) * 16 + kept_i32 % 14 if self._padded else kept_i32  # column list in W's own numbering
-        _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, dev_cols.ctypes.data, dev_cols.nbytes))
-        _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R, first_cols=self._structure_hint(mode, kept_i32))
+        _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R, first_cols=hint)
         d_stack, count = ex.stack_triangles(d_R, nc)
         if count > 1:
             _lib.tsqr_merge(d_stack, count, nc, self._d_Rm)
