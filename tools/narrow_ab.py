@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from figaroh_plus_amd import _lib
 if os.environ.get("FIGH_OLD_ABI"):  # a round-1 build: symbols added since are not there
-    for k in ("figh_regressor_build_padded", "figh_comm_available"):
+    for k in ("figh_regressor_build_padded", "figh_comm_available", "figh_place_block", "figh_host_wait_mode"):
         _lib.SIGNATURES.pop(k, None)
 from figaroh_plus_amd.pipeline import IdentificationPipeline
 from figaroh_plus_amd.tools.robot import Robot
