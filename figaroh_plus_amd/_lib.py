@@ -61,6 +61,10 @@ SIGNATURES = {
     "figh_tsqr_structured": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, _c_double_p,
                                        C.c_int, _c_int32_p, C.c_int, C.c_void_p]),
     "figh_tsqr_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "figh_select_columns": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "figh_tsqr_selected": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "figh_tsqr_merge_base": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "figh_base_permutation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "figh_regressor_colsq": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
@@ -346,3 +350,19 @@ def base_permutation(d_R, nc, n, tol_qr, d_perm):
 
 def tsqr_merge(d_Rs, count, nc, d_R):
     check(load().figh_tsqr_merge(d_Rs.ptr, count, nc, d_R.ptr))
+
+
+def select_columns(d_colsq, ncols, tol_e, link_stride, d_sel):
+    check(load().figh_select_columns(d_colsq.ptr, ncols, tol_e, link_stride, d_sel.ptr))
+
+
+def tsqr_selected(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, nblocks, n_expected, d_tau, tol_qr, d_sel, d_R):
+    """Elimination + TSQR of the kept columns back to back on the device (``n_expected`` <= 0: selection only);
+    ``tol_qr`` >= 0 folds the rank decision and the regrouped factorisation into the last merge level (figh.h)."""
+    check(load().figh_tsqr_selected(d_W.ptr, rows, ldw, d_colsq.ptr, ncols, tol_e, link_stride, nblocks, n_expected,
+                                    d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr,
+                                    d_R.ptr if d_R is not None else None))
+
+
+def tsqr_merge_base(d_Rs, count, nc, n_free, tol_qr, d_Rk):
+    check(load().figh_tsqr_merge_base(d_Rs.ptr, count, nc, n_free, tol_qr, d_Rk.ptr))

@@ -77,6 +77,12 @@ long tsqr_wide_workgroups(int nc, int cus);
 int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
                      const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out);
 
+// figh_tsqr_tree.hip: every merge level of the register-tile TSQR (nc <= 80) in one launch: `count` stacked triangles ->
+// the plain triangle d_out; d_rows_out != nullptr appends the rank decision (columns k < n_free, threshold tol) and the
+// regrouped factorisation ((nc + 1) x nc doubles, layout in figh.h).  count == 0: Rs already is the plain triangle.
+// FIGH_ERR_UNSUPPORTED when the stack is too tall for one resident grid.
+int launch_tsqr_tree(const double *Rs, long count, int nc, int n_free, double tol, double *d_out, double *d_rows_out);
+
 #define FIGH_HIP(expr)                                                                          \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \

@@ -556,6 +556,78 @@ __global__ __launch_bounds__(256) void block_sqnorm_kernel(const double *__restr
     if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
+// get_index_eliminate (regressor.py:258-279) on the device: kept = {c : not (colsq[c] < tol_e)} (NaN compares false and
+// is kept, as in the reference's loop).  sel (int32): [0] number of kept columns, [1] ncols, [2 .. 2+ncols) the kept
+// columns in W's own numbering (link_stride 16: the link-padded layout of figh_regressor_build_padded), zero-filled
+// behind the kept ones (a consumer launched with a stale count reads valid columns), [2+ncols .. 2+2 ncols) the mask.
+// tile_first (nullable): the structure hint of tsqr2_kernel -- per 64-row tile the number of kept columns in front of
+// column 14 b of the row blocks b the tile touches (joint-torque layout: row block b only involves the links >= b).
+// Every workgroup recomputes the 84..560-entry selection (cheaper than a second launch); workgroup 0 writes sel.
+__global__ __launch_bounds__(256) void select_columns_kernel(const double *__restrict__ colsq, const int ncols,
+                                                             const double tol_e, const int link_stride, const int nblocks,
+                                                             const long rows, const long rows_per_block,
+                                                             const long ntiles, int *__restrict__ sel,
+                                                             int *__restrict__ tile_first) {
+    __shared__ int kept[1024];
+    __shared__ int first[kMaxJoints];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < ncols; c += 256) kept[c] = !(colsq[c] < tol_e);
+    __syncthreads();
+    if (tile_first) {
+        for (int b = tid; b < nblocks; b += 256) {
+            const int lim = 14 * b < ncols ? 14 * b : ncols;
+            int f = 0;
+            for (int c = 0; c < lim; ++c) f += kept[c];
+            first[b] = f;
+        }
+        __syncthreads();
+        const long t = (long)blockIdx.x * 256 + tid;
+        if (t < ntiles) {
+            const long r0 = t * 64, r1 = (r0 + 63 < rows ? r0 + 63 : rows - 1);
+            int f = first[r0 / rows_per_block];
+            for (long b = r0 / rows_per_block + 1; b <= r1 / rows_per_block; ++b) f = min(f, first[b]);
+            tile_first[t] = f;
+        }
+    }
+    if (blockIdx.x != 0) return;
+    int total = 0;
+    for (int c = 0; c < ncols; ++c) total += kept[c];
+    for (int c = tid; c < ncols; c += 256) {
+        int pos = 0;
+        for (int e = 0; e < c; ++e) pos += kept[e];
+        if (kept[c]) sel[2 + pos] = (c / 14) * link_stride + c % 14;
+        if (c >= total) sel[2 + c] = 0;
+        sel[2 + ncols + c] = kept[c];
+    }
+    if (tid == 0) {
+        sel[0] = total;
+        sel[1] = ncols;
+    }
+}
+
+// Regrouped triangle -> the layout the regrouping phase of figh_tsqr_tree.hip produces: rows of qr([W1 W2 tau]) in the
+// original column order under their base column, rows of dependent columns zero, then one more row with the diagonal of
+// the plain factorisation.  Wide matrices only (nc > 80).
+__global__ __launch_bounds__(256) void scatter_regrouped_kernel(const double *__restrict__ R, const double *__restrict__ Rr,
+                                                                const int *__restrict__ perm, const int nc, const int n,
+                                                                const double tol, double *__restrict__ out) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nc * nc; e += gridDim.x * 256) {
+        const int i = e / nc, j = e - i * nc;
+        const int pi = perm[i], pj = perm[j];
+        const bool base_row = pi >= n || fabs(R[(long)pi * nc + pi]) > tol;  // the tau column is always a pivot
+        double val = (base_row && j >= i) ? Rr[e] : 0.0;
+        if (n == nc - 1 && e == nc * nc - 1) {  // (tau, tau): the residual || tau - W1 phi || = what lies below the base rows
+            int r = 0;
+            for (int k = 0; k < n; ++k) r += fabs(R[(long)k * nc + k]) > tol;
+            double ss = 0.0;
+            for (int k = r; k < nc; ++k) ss += Rr[(long)k * nc + n] * Rr[(long)k * nc + n];
+            val = sqrt(ss);
+        }
+        out[(long)pi * nc + pj] = val;
+        if (i == 0) out[(long)nc * nc + j] = R[(long)j * nc + j];
+    }
+}
+
 static int cu_count() {
     static int cus = 0;
     if (!cus) {
@@ -638,6 +710,10 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
 //             start at their first non-zero column).
 static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out) {
     const size_t tri = sizeof(double) * (size_t)nc * nc;
+    if (nc <= 80 && count > 1) {  // every level in one launch (figh_tsqr_tree.hip) when the stack fits one resident grid
+        const int rc = launch_tsqr_tree(Rs, count, nc, 0, 0.0, d_R_out, nullptr);
+        if (rc != FIGH_ERR_UNSUPPORTED) return rc;
+    }
     const double *cur = Rs;
     long cnt = count;
     int slot = 2;
@@ -901,6 +977,98 @@ int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out) {
         return FIGH_OK;
     }
     return tsqr_reduce(d_Rs, count, nc, d_R_out);
+}
+
+
+int figh_select_columns(const double *d_colsq, int ncols, double tol_e, int link_stride, int32_t *d_sel) {
+    FIGH_REQUIRE(d_colsq && d_sel, "NULL device pointer");
+    FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_select_columns: 1 .. 1024 columns");
+    FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
+    if (int rc = ensure_device()) return rc;
+    ProfileScope scope("select_columns");
+    hipLaunchKernelGGL(select_columns_kernel, dim3(1), dim3(256), 0, stream(), d_colsq, ncols, tol_e, link_stride, 0, 0L,
+                       1L, 0L, d_sel, (int *)nullptr);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+// plain triangle -> rows of the regrouped factorisation in the original column order + the plain diagonal (see figh.h)
+static int reveal_triangle(const double *d_R, int nc, int n_free, double tol_qr, double *d_rows_out) {
+    if (nc <= 80) return launch_tsqr_tree(d_R, 0, nc, n_free, tol_qr, nullptr, d_rows_out);
+    int *perm = static_cast<int *>(workspace(sizeof(int) * (size_t)nc, 17));
+    double *Rr = static_cast<double *>(workspace(sizeof(double) * (size_t)nc * nc, 18));
+    if (!perm || !Rr) return FIGH_ERR_ALLOC;
+    if (int rc = figh_base_permutation(d_R, nc, n_free, tol_qr, perm)) return rc;
+    if (int rc = figh_tsqr(d_R, nc, nc, perm, nc, nullptr, nullptr, 0, Rr)) return rc;
+    ProfileScope scope("scatter_regrouped");
+    hipLaunchKernelGGL(scatter_regrouped_kernel, dim3(64), dim3(256), 0, stream(), d_R, Rr, perm, nc, n_free, tol_qr,
+                       d_rows_out);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+// stack of `count` triangles -> one; tol_qr >= 0: + rank decision and regrouped rows ((nc+1) x nc), else the plain triangle
+static int reduce_stack(const double *d_Rs, long count, int nc, int n_free, double tol_qr, double *d_out) {
+    if (tol_qr < 0.0) return figh_tsqr_merge(d_Rs, (int)count, nc, d_out);
+    double *one = static_cast<double *>(workspace(sizeof(double) * (size_t)nc * nc, 16));
+    if (!one) return FIGH_ERR_ALLOC;
+    if (count == 1) {
+        if (nc <= 80) return reveal_triangle(d_Rs, nc, n_free, tol_qr, d_out);  // (one launch, touches no workspace)
+        // the wide regrouping runs figh_tsqr again, whose level 0 reuses the workspace d_Rs may live in
+        FIGH_HIP(hipMemcpyAsync(one, d_Rs, sizeof(double) * (size_t)nc * nc, hipMemcpyDeviceToDevice, stream()));
+        return reveal_triangle(one, nc, n_free, tol_qr, d_out);
+    }
+    if (nc <= 80) {
+        const int rc = launch_tsqr_tree(d_Rs, count, nc, n_free, tol_qr, one, d_out);
+        if (rc != FIGH_ERR_UNSUPPORTED) return rc;
+    }
+    if (int rc = tsqr_reduce(d_Rs, count, nc, one)) return rc;
+    return reveal_triangle(one, nc, n_free, tol_qr, d_out);
+}
+
+int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                       int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
+                       double *d_R_out) {
+    FIGH_REQUIRE(d_W && d_colsq && d_sel, "NULL device pointer");
+    FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
+    FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
+    FIGH_REQUIRE(rows > 0 && n_expected <= ncols, "bad shape");
+    FIGH_REQUIRE(nblocks >= 0 && nblocks <= kMaxJoints && (nblocks == 0 || rows % nblocks == 0),
+                 "rows must be a multiple of the hint blocks");
+    if (int rc = ensure_device()) return rc;
+    const int nc = n_expected + (d_tau ? 1 : 0);
+    const bool hinted = nblocks > 0 && n_expected > 0 && nc <= 80 && rows / nblocks >= 1;
+    const long ntiles = (rows + 63) / 64;
+    int *d_tile = nullptr;
+    if (hinted) {
+        d_tile = static_cast<int *>(workspace(sizeof(int) * (size_t)(ntiles + 1), 19));
+        if (!d_tile) return FIGH_ERR_ALLOC;
+    }
+    {
+        ProfileScope scope("select_columns");
+        const long grid = hinted ? (ntiles + 255) / 256 : 1;
+        hipLaunchKernelGGL(select_columns_kernel, dim3((unsigned)grid), dim3(256), 0, stream(), d_colsq, ncols, tol_e,
+                           link_stride, hinted ? nblocks : 0, (long)rows, hinted ? (long)(rows / nblocks) : 1L,
+                           hinted ? ntiles : 0L, d_sel, d_tile);
+        FIGH_HIP(hipGetLastError());
+    }
+    if (n_expected <= 0) return FIGH_OK;  // selection only (the caller does not know the count yet)
+    FIGH_REQUIRE(d_R_out, "NULL device pointer");
+    g_tile_hint = d_tile;  // consumed by the level-0 launch below
+    int64_t nw = 0;
+    double *Rws = nullptr;
+    const int rc0 = figh_tsqr_level0(d_W, rows, ldw, d_sel + 2, n_expected, d_tau, nullptr, 0, nullptr, 0, &nw, &Rws);
+    g_tile_hint = nullptr;
+    if (rc0) return rc0;
+    return reduce_stack(Rws, nw, nc, n_expected, tol_qr, d_R_out);
+}
+
+int figh_tsqr_merge_base(const double *d_Rs, int count, int nc, int n_free, double tol_qr, double *d_Rk_out) {
+    FIGH_REQUIRE(d_Rs && d_Rk_out, "NULL device pointer");
+    FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 512 && n_free >= 1 && n_free <= nc, "bad shape");
+    FIGH_REQUIRE(tol_qr >= 0.0, "tol_qr must be non-negative");
+    if (int rc = ensure_device()) return rc;
+    return reduce_stack(d_Rs, count, nc, n_free, tol_qr, d_Rk_out);
 }
 
 }  // extern "C"

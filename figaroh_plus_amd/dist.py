@@ -60,6 +60,16 @@ class TorchExchange:
     def sum_columns(self, d_colsq, ncols):
         return self.allreduce_sum_host(d_colsq.to_host())
 
+    def sum_columns_device(self, d_colsq, ncols):
+        """Host-staged: the sum is written back so that the device-side selection sees the global norms."""
+        from . import _lib
+
+        mine = np.empty(ncols)
+        lib = _lib.load()
+        _lib.check(lib.figh_memcpy_d2h(mine.ctypes.data, d_colsq.ptr, mine.nbytes))
+        total = np.ascontiguousarray(self.allreduce_sum_host(mine))
+        _lib.check(lib.figh_memcpy_h2d(d_colsq.ptr, total.ctypes.data, total.nbytes))
+
     def stack_triangles(self, d_R, nc):
         from . import _lib
 
@@ -88,6 +98,9 @@ class RcclExchange:
     def sum_columns(self, d_colsq, ncols):
         self._lib.check(self._lib.load().figh_comm_allreduce_sum(d_colsq.ptr, ncols))
         return d_colsq.to_host()
+
+    def sum_columns_device(self, d_colsq, ncols):
+        self._lib.check(self._lib.load().figh_comm_allreduce_sum(d_colsq.ptr, ncols))
 
     def stack_triangles(self, d_R, nc):
         need = self.world_size * nc * nc

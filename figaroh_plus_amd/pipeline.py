@@ -30,6 +30,9 @@ class Exchange:
     def sum_columns(self, d_colsq, ncols):
         return d_colsq.to_host()
 
+    def sum_columns_device(self, d_colsq, ncols):
+        """In place: d_colsq holds the sum over the ranks afterwards; nothing returns to the host."""
+
     def stack_triangles(self, d_R, nc):
         return d_R, 1
 
@@ -146,17 +149,15 @@ class IdentificationPipeline:
         mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
         dm = self.robot.device_model()
         rps, ncols = dm.shape(mode, flags)
-        if getattr(self, "_d_colsq", None) is None or self._d_colsq.size != ncols:
+        if getattr(self, "_dc_colsq", None) is None or self._dc_colsq.size != ncols:
             cap = ncols + 1
-            self._d_colsq = _lib.DeviceArray((ncols,), np.float64)
-            self._d_idx = _lib.DeviceArray((cap,), np.int32)
-            self._d_Rm = _lib.DeviceArray((cap * cap,), np.float64)
-            self._d_Rp = _lib.DeviceArray((cap * cap,), np.float64)
-            self._d_R2 = _lib.DeviceArray((cap * cap,), np.float64)
+            self._dc_colsq = _lib.DeviceArray((ncols,), np.float64)
+            self._dc_idx = _lib.DeviceArray((cap,), np.int32)
+            self._dc_R = _lib.DeviceArray((cap * cap,), np.float64)
         # pass 1: column norms
-        _lib.regressor_colsq(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._d_colsq,
+        _lib.regressor_colsq(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._dc_colsq,
                              chunk_samples=self.chunk_samples)
-        col_norm = ex.sum_columns(self._d_colsq, ncols)
+        col_norm = ex.sum_columns(self._dc_colsq, ncols)
         idx_e = [i for i in range(ncols) if col_norm[i] < self.tol_e]
         kept = [i for i in range(ncols) if not col_norm[i] < self.tol_e]
         params_r = [self.names[i] for i in kept]
@@ -164,28 +165,20 @@ class IdentificationPipeline:
         with_tau = self.d_tau is not None
         nc = n + (1 if with_tau else 0)
         kept_i32 = np.asarray(kept, dtype=np.int32)
-        _lib.check(lib.figh_memcpy_h2d(self._d_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
+        _lib.check(lib.figh_memcpy_h2d(self._dc_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
         # pass 2: every chunk rebuilt and factored, triangles merged
-        d_R = self._d_Rm
-        _lib.regressor_tsqr(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._d_idx, n,
+        d_R = self._dc_R
+        _lib.regressor_tsqr(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._dc_idx, n,
                             self.d_tau if with_tau else None, None, d_R, chunk_samples=self.chunk_samples)
         d_stack, count = ex.stack_triangles(d_R, nc)
-        if count > 1:
-            d_R = _lib.DeviceArray((nc * nc,), np.float64)
-            _lib.tsqr_merge(d_stack, count, nc, d_R)
-        return self._tail(d_R, n, nc, params_r, idx_e, col_norm, with_tau, rps * self.N * ex.world_size, strings)
-
-    def _structure_hint(self, mode, kept_i32):
-        """Joint-torque regressor of single-dof joints (regressor.py:45-87): the rows of joint j (row block j of N rows)
-        only involve the links of j's subtree, which are numbered from j on -- the columns in front of 14 j are zeros
-        written by K1.  Returns, per row block, how many kept columns lie in front (None when the structure is not
-        guaranteed: external-wrench mode, multi-dof joints)."""
-        m = self.robot.model
-        if mode != _lib.MODE_JOINT_TORQUE or m.nv != m.njoints - 1 or self.N < 64:
-            return None
-        return np.searchsorted(kept_i32, 14 * np.arange(m.nv)).astype(np.int32)
+        return self._tail(d_stack, count, n, nc, params_r, idx_e, col_norm, with_tau, rps * self.N * ex.world_size, strings)
 
     def run(self, strings=True):
+        """One pass.  Nothing returns to the host before the end: K1 leaves diag(W^T W) in HBM, the kept-column list is
+        formed there (figh_tsqr_selected), the TSQR is launched with the column COUNT of the previous pass, the merge tree
+        ends in the rank-revealing level, and one copy brings back [column norms | selection | triangle rows].  The count
+        is verified against the device's own afterwards; the first pass (count unknown) and a pass whose count changed
+        repeat the solve with the right one."""
         if self._chunked():
             return self._run_chunked(strings)
         ex = self.exchange
@@ -195,6 +188,7 @@ class IdentificationPipeline:
         handle = self.robot.device_model()
         if self.W is None:  # HBM buffers are allocated once and reused by every step
             self._kept_cache = None
+            self._n_expected = -1
             rows_per_sample, ncols = handle.shape(mode, flags)
             # W stays in HBM.  Chains: the reference's dense layout (the chain kernel streams one contiguous run per tile).
             # Trees: the link-padded layout of figh_regressor_build_padded -- 16 columns per link, every (row, link)
@@ -207,81 +201,101 @@ class IdentificationPipeline:
                 self.W = GpuMatrix.empty(rows_per_sample * self.N, ncols)
                 self.W.ref_cols = ncols
             cap = ncols + 1
-            self._d_colsq = _lib.DeviceArray((ncols,), np.float64)
-            self._d_idx = _lib.DeviceArray((cap,), np.int32)
+            # one buffer for everything that returns to the host: [colsq (ncols f64) | sel (2 + 2 ncols i32) | rows ((cap+1) cap f64)]
+            self._sel_words = (2 + 2 * ncols + 1) // 2
+            self._d_pack = _lib.DeviceArray((ncols + self._sel_words + (cap + 1) * cap,), np.float64)
+            self._d_colsq = _View(self._d_pack, 0)
+            self._d_sel = _View(self._d_pack, ncols * 8)
+            self._d_rows = _View(self._d_pack, (ncols + self._sel_words) * 8)
             self._d_R = _lib.DeviceArray((cap * cap,), np.float64)
-            self._d_Rm = _lib.DeviceArray((cap * cap,), np.float64)
-            self._d_Rp = _lib.DeviceArray((cap * cap,), np.float64)
-            self._d_R2 = _lib.DeviceArray((cap * cap,), np.float64)
+            # joint-torque regressor of single-dof joints (regressor.py:45-87): the rows of joint j (row block j of N rows)
+            # only involve the links of j's subtree, which are numbered from j on -- the columns in front of 14 j are
+            # zeros written by K1; the device derives the per-tile form of that hint from its own column list
+            m = self.robot.model
+            structured = mode == _lib.MODE_JOINT_TORQUE and m.nv == m.njoints - 1 and self.N >= 64
+            self._hint_blocks = m.nv if structured else 0
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
         if self._padded:
             _lib.regressor_build_padded(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld,
                                         d_colsq)
         else:
             _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
-        col_norm = ex.sum_columns(d_colsq, W.ref_cols)
-        small = col_norm < self.tol_e  # regressor.py:271-277 (NaN compares False: kept, as in the reference's loop)
-        d_R, d_idx = self._d_R, self._d_idx
-        cached = getattr(self, "_kept_cache", None)
-        if cached is not None and np.array_equal(cached[0], small):
-            # the same columns as in the previous pass: the lists derived from the mask and the column list that is
-            # already in HBM are reused (the decision itself is taken afresh from this pass's norms every time)
-            _, idx_e, params_r, n, hint = cached
+        ex.sum_columns_device(d_colsq, W.ref_cols)
+        ncols, with_tau = W.ref_cols, self.d_tau is not None
+        stride = 16 if self._padded else 14
+        for attempt in range(3):
+            n = self._n_expected
+            nc = n + (1 if with_tau else 0)
+            if ex.world_size == 1:
+                _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
+                                   self.tol_qr, self._d_sel, self._d_rows)
+            else:
+                _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
+                                   -1.0, self._d_sel, self._d_R)
+                if n > 0:
+                    d_stack, count = ex.stack_triangles(self._d_R, nc)
+                    _lib.tsqr_merge_base(d_stack, count, nc, n, self.tol_qr, self._d_rows)
+            words = ncols + self._sel_words + ((nc + 1) * nc if n > 0 else 0)
+            host = np.empty(words)
+            _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, self._d_pack.ptr, host.nbytes))
+            sel = host[ncols:ncols + self._sel_words].view(np.int32)
+            if int(sel[0]) == n:
+                break
+            self._n_expected = int(sel[0])  # first pass, or the kept set changed size: solve again with the right shape
+            if self._n_expected == 0:
+                raise ValueError("every column of the regressor was eliminated")
+        else:
+            raise RuntimeError("the number of kept columns did not settle")
+        col_norm = host[:ncols].copy()
+        kept_mask = sel[2 + ncols:2 + 2 * ncols] != 0
+        cached = self._kept_cache
+        if cached is not None and np.array_equal(cached[0], kept_mask):
+            _, idx_e, params_r = cached  # same columns as in the previous pass: the derived lists are reused
             idx_e, params_r = list(idx_e), list(params_r)  # (the caller owns what run() returns)
         else:
-            idx_e = np.flatnonzero(small).tolist()
-            kept_i32 = np.flatnonzero(~small).astype(np.int32)
-            params_r = [self.names[i] for i in kept_i32.tolist()]
-            n = len(params_r)
-            dev_cols = (kept_i32 // 14) * 16 + kept_i32 % 14 if self._padded else kept_i32  # W's own column numbering
-            _lib.check(lib.figh_memcpy_h2d(d_idx.ptr, dev_cols.ctypes.data, dev_cols.nbytes))
-            hint = self._structure_hint(mode, kept_i32)
-            self._kept_cache = (small.copy(), list(idx_e), list(params_r), n, hint)
-        # K3: TSQR over the kept columns (+ tau), then the cross-rank stack
-        with_tau = self.d_tau is not None
-        nc = n + (1 if with_tau else 0)
-        _lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, self.d_tau, None, d_R, first_cols=hint)
-        d_stack, count = ex.stack_triangles(d_R, nc)
-        if count > 1:
-            _lib.tsqr_merge(d_stack, count, nc, self._d_Rm)
-            d_R = self._d_Rm
-        return self._tail(d_R, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+            idx_e = np.flatnonzero(~kept_mask).tolist()
+            params_r = [self.names[i] for i in np.flatnonzero(kept_mask).tolist()]
+            self._kept_cache = (kept_mask.copy(), list(idx_e), list(params_r))
+        rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
+        return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
 
-    def _tail(self, d_R, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
+    def _tail(self, d_stack, count, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
+        """Stack of plain triangles in HBM (one per rank) -> results: reduction, rank decision and regrouped factorisation
+        on the device (figh_tsqr_merge_base), one copy back."""
         lib = _lib.load()
-        # tail on the n x n triangle (qrdecomposition.py:215-266).  The rank decision |R_ii| > tol and the regrouped
-        # order [base | rest | tau] are formed on the device (figh_base_permutation) and the regrouped factorisation
-        # qr(R[:, perm]) goes through the TSQR kernel again (column gather in the kernel, one wavefront), so the whole
-        # tail needs ONE host round trip: R, the regrouped triangle and the permutation come back in one copy.
-        words = 2 * nc * nc + (nc + 1) // 2
-        pack = getattr(self, "_d_pack", None)
-        if pack is None or pack.size < words:
-            pack = self._d_pack = _lib.DeviceArray((words,), np.float64)
-        _lib.check(lib.figh_memcpy_d2d(pack.ptr, d_R.ptr, nc * nc * 8))
-        d_perm = _View(pack, 2 * nc * nc * 8)
-        _lib.base_permutation(d_R, nc, n, self.tol_qr, d_perm)
-        _lib.tsqr(d_R, nc, nc, d_perm, nc, None, None, _View(pack, nc * nc * 8))
-        host = np.empty(words)
+        pack = getattr(self, "_d_tailpack", None)
+        if pack is None or pack.size < (nc + 1) * nc:
+            pack = self._d_tailpack = _lib.DeviceArray(((nc + 1) * nc,), np.float64)
+        _lib.tsqr_merge_base(d_stack, count, nc, n, self.tol_qr, pack)
+        host = np.empty((nc + 1) * nc)
         _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, pack.ptr, host.nbytes))
-        R = host[:nc * nc].reshape(nc, nc)          # upper triangular: the kernels write the zeros
-        R_r = host[nc * nc:2 * nc * nc].reshape(nc, nc)
-        perm = host[2 * nc * nc:].view(np.int32)[:nc]
-        r = int(np.count_nonzero(np.abs(np.diag(R)[:n]) > self.tol_qr))
-        idx_base, idx_regroup = perm[:r].tolist(), perm[r:n].tolist()
+        return self._finish(host.reshape(nc + 1, nc), n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings)
+
+    def _finish(self, rows_k, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
+        """Host tail on the n x n numbers the device returns (qrdecomposition.py:215-266): ``rows_k`` ((nc + 1) x nc) holds,
+        in the original column order, the rows of the regrouped factorisation qr([W1 W2 tau]) at the base columns and, in
+        its last row, the diagonal of the plain factorisation (include/figh.h, figh_tsqr_selected)."""
+        diag = np.abs(rows_k[nc])
+        rows_k = rows_k[:nc]
+        base_mask = diag[:n] > self.tol_qr  # the device took the same decision on the same numbers
+        base = np.flatnonzero(base_mask)
+        rest = np.flatnonzero(~base_mask)
+        idx_base, idx_regroup = base.tolist(), rest.tolist()
         assert len(params_r) == n, "params_r does not have same length with R"
-        r = len(idx_base)
-        R1, R2, z = R_r[:r, :r], R_r[:r, r:n], (R_r[:r, n] if with_tau else None)
-        # inv(R1) of qrdecomposition.py:244 by LAPACK's triangular inverse (dtrtri): R1 is upper triangular, and
-        # np.linalg.inv's general LU path pays ~30 us of BLAS thread start-up per call on a many-core host
+        Rb = rows_k[base]
+        R1, R2, z = Rb[:, base], Rb[:, rest], (Rb[:, n] if with_tau else None)
+        # inv(R1) of qrdecomposition.py:244 by LAPACK's triangular inverse (dtrtri): R1 is upper triangular (the routine
+        # reads the upper triangle only; below it the device leaves rounding residues), and np.linalg.inv's general LU
+        # path pays ~30 us of BLAS thread start-up per call on a many-core host
         with _single_threaded_blas(n):
-            R1_inv, info = _dtrtri(R1)
+            R1_inv, info = _dtrtri(np.ascontiguousarray(R1))
             if info != 0:
                 raise np.linalg.LinAlgError("Singular matrix")
             beta = np.around(R1_inv @ R2, 6)
             phi_ls = R1_inv @ z if with_tau else None
         out = {
             "idx_e": idx_e, "params_r": params_r, "idx_base": idx_base, "beta": beta,
-            "col_norm": col_norm, "absdiagR": np.abs(np.diag(R)[:n]), "rows": total_rows,
+            "col_norm": col_norm, "absdiagR": diag[:n].copy(), "rows": total_rows,
         }
         if strings:
             out["params_base"] = qrd._expressions([params_r[i] for i in idx_base],
@@ -289,5 +303,5 @@ class IdentificationPipeline:
         if with_tau:
             out["phi_b"] = np.round(phi_ls, 6)
             out["phi_ls"] = phi_ls
-            out["residual_norm"] = abs(R[n, n])
+            out["residual_norm"] = abs(float(rows_k[n, n]))
         return out

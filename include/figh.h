@@ -157,6 +157,35 @@ int figh_base_permutation(const double *d_R, int nc, int n, double tol_qr, int32
 /* Sample-sharded reduction step: QR of `count` stacked nc x nc R factors (d_Rs: count*nc x nc) into one. */
 int figh_tsqr_merge(const double *d_Rs, int count, int nc, double *d_R_out);
 
+/* ---- the elimination and the base-parameter factorisation without a host round trip (IdentificationPipeline)
+ * figh_select_columns: get_index_eliminate (regressor.py:258-279) on the device.  d_sel (2 + 2 ncols int32):
+ * [0] the number of kept columns {c : not (colsq[c] < tol_e)}, [1] ncols, [2 .. 2+ncols) the kept columns in W's own
+ * numbering (link_stride 14: the reference layout; 16: the link-padded layout, column 16 (c / 14) + c % 14), zeros behind
+ * them, [2+ncols .. 2+2 ncols) the 0/1 mask in the reference's numbering. */
+int figh_select_columns(const double *d_colsq, int ncols, double tol_e, int link_stride, int32_t *d_sel);
+/* figh_tsqr_selected: figh_select_columns followed by the TSQR of W[:, kept] (+ tau), launched back to back: the column
+ * list never visits the host.  The launch shape needs the column COUNT, which the caller supplies as n_expected (the
+ * count of the previous pass; <= 0: selection only) and verifies afterwards against d_sel[0] -- on a mismatch the result
+ * is to be discarded and the call repeated with the right count (entries of the list behind the device's count are 0,
+ * so a stale count reads valid columns).  nblocks > 0: the structure hint of figh_tsqr_structured, derived from the list
+ * on the device (row block b of rows/nblocks rows only involves the reference columns >= 14 b).
+ * tol_qr < 0: d_R_out is the plain nc x nc triangle of figh_tsqr.
+ * tol_qr >= 0: the rank decision and the regrouped factorisation of get_baseParams / double_QR
+ * (qrdecomposition.py:205-244, :105-160) follow in the same launch as the last merge level.  d_R_out then is
+ * (nc + 1) x nc: rows 0 .. nc-1 hold, in the ORIGINAL column order, row k = the row of qr([W1 W2 tau]) that belongs to
+ * base column k (W1 = the columns with |R_kk| > tol_qr in the plain factorisation qr([W_e tau]), W2 the others), i.e.
+ * R1 = out[base][:, base] (its upper triangle), R2 = out[base][:, rest], Q1^T tau = out[base][:, n]; the rows of
+ * dependent columns are zero, and with exactly one extra column (tau) out[n][n] = || tau - W1 phi ||, the residual of the
+ * least-squares problem in base coordinates.  Row nc is the diagonal of the plain factorisation: the numbers the rank
+ * decision was taken on. */
+int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                       int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
+                       double *d_R_out);
+/* figh_tsqr_merge followed by the rank decision and the regrouped factorisation as in figh_tsqr_selected (the cross-rank
+ * reduction of the all-gathered per-rank triangles): columns k < n_free take part in the rank decision, the others (tau)
+ * always count as base columns.  d_rows_out: (nc + 1) x nc. */
+int figh_tsqr_merge_base(const double *d_Rs, int count, int nc, int n_free, double tol_qr, double *d_rows_out);
+
 /* ------------------------------------------------------------------ streamed entry points (W never stored in full)
  * The "fused" forms of SURVEY.md section 8b: the samples are processed in chunks of `chunk_samples` (0 = library
  * default, about 2 GB of W); each chunk's W lives in a library workspace only until the next kernel has consumed it.

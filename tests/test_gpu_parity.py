@@ -1008,3 +1008,185 @@ def test_tsqr_randomised_stress(lib):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tsqr_stress.py"), "60", "20250410"],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert out.returncode == 0 and b"all 60 cases ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ round 3: no host round trip
+def _rows_to_blocks(rows_k, n, tol):
+    d = np.abs(rows_k[-1])
+    rows_k = rows_k[:-1]
+    base = np.flatnonzero(d[:n] > tol)
+    rest = np.flatnonzero(~(d[:n] > tol))
+    Rb = rows_k[base]
+    return base, rest, np.triu(Rb[:, base]), Rb[:, rest], d
+
+
+@pytest.mark.parametrize("stride", [14, 16])
+def test_select_columns_on_device(lib, stride):
+    """get_index_eliminate (regressor.py:258-279) on the device: mask, compacted list in W's numbering, NaN kept."""
+    rng = np.random.default_rng(3)
+    for ncols in (1, 14, 84, 87 if stride == 14 else 96, 560):
+        cs = rng.uniform(0.0, 2e-6, ncols)
+        cs[rng.integers(0, ncols, 3)] = 0.0
+        if ncols > 20:
+            cs[7] = np.nan
+            cs[11] = 1e-6  # not < tol: kept
+        d_cs = lib.DeviceArray.from_host(cs)
+        d_sel = lib.DeviceArray((2 + 2 * ncols,), np.int32)
+        lib.select_columns(d_cs, ncols, 1e-6, stride, d_sel)
+        sel = d_sel.to_host()
+        kept = np.flatnonzero(~(cs < 1e-6))
+        assert sel[0] == len(kept) and sel[1] == ncols
+        assert np.array_equal(sel[2:2 + len(kept)], (kept // 14) * stride + kept % 14)
+        assert not sel[2 + len(kept):2 + ncols].any()
+        assert np.array_equal(sel[2 + ncols:] != 0, ~(cs < 1e-6))
+
+
+@pytest.mark.parametrize("nc,count", [(1, 5), (17, 40), (50, 2), (50, 16), (50, 300), (50, 2039), (64, 700), (65, 9), (80, 130),
+                                      (49, 4500)])
+def test_merge_tree_against_lapack(lib, nc, count):
+    """figh_tsqr_merge: every level in one launch (figh_tsqr_tree.hip) -- one, two and three levels, both tile
+    geometries, and the stack that is too tall for one resident grid (4500 triangles: per-level launches)."""
+    rng = np.random.default_rng(nc * 1000 + count)
+    stack = np.triu(rng.standard_normal((count, nc, nc)))
+    stack[:, :, nc // 2] *= 1e-3
+    d_stack = lib.DeviceArray.from_host(stack.reshape(-1))
+    d_R = lib.DeviceArray((nc * nc,))
+    lib.tsqr_merge(d_stack, count, nc, d_R)
+    R = d_R.to_host().reshape(nc, nc)
+    assert np.array_equal(R, np.triu(R))
+    ref = np.linalg.qr(stack.reshape(-1, nc), mode="r")
+    assert np.abs(np.abs(R) - np.abs(ref)).max() <= 1e-12 * np.abs(ref).max()
+    # bit-reproducible
+    lib.tsqr_merge(d_stack, count, nc, d_R)
+    assert np.array_equal(d_R.to_host().reshape(nc, nc), R)
+
+
+@pytest.mark.parametrize("nc,count,with_tau", [(50, 1, True), (50, 8, True), (37, 200, False), (70, 33, True), (50, 2039, True),
+                                               (120, 3, True), (200, 1, False)])
+def test_merge_base_rank_revealing_level(lib, nc, count, with_tau):
+    """figh_tsqr_merge_base: the rows of qr([W1 W2 tau]) in the original column order + the pivots of the plain
+    factorisation, against NumPy on the same stack (qrdecomposition.py:205-244)."""
+    rng = np.random.default_rng(nc + count)
+    n = nc - (1 if with_tau else 0)
+    # a stack whose columns have exact dependencies: every third column is a combination of earlier ones
+    rows = max(4 * nc, count * nc)
+    A = rng.standard_normal((rows, nc))
+    dep = [k for k in range(2, n) if k % 3 == 2]
+    for k in dep:
+        A[:, k] = A[:, :k] @ rng.standard_normal(k) * 0.3
+    parts = np.array_split(A, count)
+    stack = np.stack([np.linalg.qr(p, mode="r") if p.shape[0] >= nc else
+                      np.vstack([np.linalg.qr(p, mode="r"), np.zeros((nc - p.shape[0], nc))]) for p in parts])
+    d_stack = lib.DeviceArray.from_host(stack.reshape(-1))
+    d_out = lib.DeviceArray(((nc + 1) * nc,))
+    tol = 1e-8
+    lib.tsqr_merge_base(d_stack, count, nc, n, tol, d_out)
+    rows_k = d_out.to_host().reshape(nc + 1, nc)
+    base, rest, R1, R2, d = _rows_to_blocks(rows_k, n, tol)
+    Rp = np.linalg.qr(A, mode="r")
+    assert base.tolist() == [k for k in range(n) if k not in dep]
+    assert base.tolist() == np.flatnonzero(np.abs(np.diag(Rp))[:n] > tol).tolist()
+    # diagonal of the plain factorisation.  Up to the first dependent column it is LAPACK's; behind it every
+    # implementation's reflector of a dependent column points along its own rounding noise and takes a different (small)
+    # part of the later columns with it, so only |R_kk| <= dist(column k, span of the base columns before it) = |R1_ii|
+    # is implementation independent there.  Dependent columns sit at roundoff level.
+    dp = np.abs(np.diag(Rp))
+    first_dep = dep[0] if dep else n
+    assert np.abs(d[:first_dep] - dp[:first_dep]).max() <= 1e-11 * dp.max()
+    assert (d[base] <= np.abs(np.diag(R1)) * (1 + 1e-11)).all() and d[base].min() > 1e-3
+    assert d[rest].max(initial=0.0) <= 1e-10 * dp.max()
+    rows_k = rows_k[:nc]
+    # regrouped factorisation
+    perm = base.tolist() + rest.tolist() + ([n] if with_tau else [])
+    Rr = np.linalg.qr(A[:, perm], mode="r")
+    r = len(base)
+    assert np.abs(np.abs(R1) - np.abs(Rr[:r, :r])).max() <= 1e-11 * np.abs(Rr).max()
+    beta = np.linalg.solve(R1, R2)
+    beta_ref = np.linalg.solve(Rr[:r, :r], Rr[:r, r:n])
+    assert np.abs(beta - beta_ref).max() <= 1e-9 * max(1.0, np.abs(beta_ref).max())
+    assert not rows_k[rest].any()  # rows of dependent columns are empty
+    if with_tau:
+        phi = np.linalg.solve(R1, rows_k[base][:, n])
+        phi_ref = np.linalg.lstsq(A[:, base], A[:, n], rcond=None)[0]
+        assert np.abs(phi - phi_ref).max() <= 1e-9 * max(1.0, np.abs(phi_ref).max())
+        res = np.linalg.norm(A[:, n] - A[:, base] @ phi_ref)
+        assert abs(abs(rows_k[n, n]) - res) <= 1e-9 * max(1.0, res)
+
+
+def test_tsqr_selected_matches_host_flow(lib, golden):
+    """figh_tsqr_selected: elimination + TSQR + rank-revealing merge without a host round trip == the reference's
+    sequence get_index_eliminate -> build_regressor_reduced -> get_baseParams on the same W (all five configs; chains in
+    the reference layout with the structure hint, trees in the link-padded layout)."""
+    from figaroh_plus_amd.tools.regressor import build_regressor_device, regressor_flags
+    g = golden
+    robot = g.robot()
+    q, v, a = g["q_big"], g["v_big"], g["a_big"]
+    N = len(q)
+    dq, dv, da = (lib.DeviceArray.from_host(np.ascontiguousarray(x).reshape(-1)) for x in (q, v, a))
+    W, colsq = build_regressor_device(robot, dq, dv, da, N, g.param, coupling=g.coupling, colsq=True)
+    ncols = W.cols
+    mode, _, _ = regressor_flags(g.param, g.coupling)
+    m = robot.model
+    nblocks = m.nv if (mode == lib.MODE_JOINT_TORQUE and m.nv == m.njoints - 1 and N >= 64) else 0
+    d_tau = lib.DeviceArray.from_host(g["tau"])
+    d_sel = lib.DeviceArray((2 + 2 * ncols,), np.int32)
+    # selection only (count unknown), then a stale count, then the right one
+    lib.tsqr_selected(W.buf, W.rows, W.ld, colsq, ncols, 1e-6, 14, nblocks, -1, d_tau, 1e-8, d_sel, None)
+    sel = d_sel.to_host()
+    kept = [i for i in range(ncols) if i not in set(g["idx_e"].tolist())]
+    n = len(kept)
+    assert sel[0] == n and sel[2:2 + n].tolist() == kept
+    d_rows = lib.DeviceArray(((n + 2) * (n + 1),))
+    lib.tsqr_selected(W.buf, W.rows, W.ld, colsq, ncols, 1e-6, 14, nblocks, n - 1, d_tau, 1e-8, d_sel, d_rows)
+    assert d_sel.to_host()[0] == n  # the device reports its own count whatever the caller expected
+    lib.tsqr_selected(W.buf, W.rows, W.ld, colsq, ncols, 1e-6, 14, nblocks, n, d_tau, 1e-8, d_sel, d_rows)
+    rows_k = d_rows.to_host().reshape(n + 2, n + 1)
+    base, rest, R1, R2, d = _rows_to_blocks(rows_k, n, 1e-8)
+    assert base.tolist() == list(g["idx_base"])
+    beta = np.around(np.linalg.solve(R1, R2), 6)
+    from figaroh_plus_amd.tools.qrdecomposition import _expressions
+    params_r = g.meta["params_r"]
+    assert _expressions([params_r[i] for i in base], [params_r[i] for i in rest], beta) == g.meta["params_base"]
+    phi = np.linalg.solve(R1, rows_k[base][:, n])
+    assert np.abs(phi - g["phi_pinv"]).max() <= 1e-6 * np.abs(g["phi_pinv"]).max()
+    # plain triangle (tol < 0) == figh_tsqr on the same columns
+    d_R = lib.DeviceArray(((n + 1) * (n + 1),))
+    lib.tsqr_selected(W.buf, W.rows, W.ld, colsq, ncols, 1e-6, 14, nblocks, n, d_tau, -1.0, d_sel, d_R)
+    R = d_R.to_host().reshape(n + 1, n + 1)
+    d_idx = lib.DeviceArray.from_host(np.asarray(kept, dtype=np.int32))
+    d_R2 = lib.DeviceArray(((n + 1) * (n + 1),))
+    lib.tsqr(W.buf, W.rows, W.ld, d_idx, n, d_tau, None, d_R2)
+    R2_ = d_R2.to_host().reshape(n + 1, n + 1)
+    assert np.abs(np.abs(R) - np.abs(R2_)).max() <= 1e-11 * np.abs(R2_).max()
+    assert np.abs(np.abs(np.diag(R)) - d).max() <= 1e-11 * d.max()
+
+
+def test_pipeline_recovers_when_the_kept_set_changes(lib, golden_ur10):
+    """The pass is launched with the previous pass's column count; data with another elimination pattern must be
+    detected from the device's own count and solved again (no stale shape, no stale list)."""
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic, get_index_eliminate
+    from figaroh_plus_amd.tools.qrdecomposition import get_baseIndex
+    g = golden_ur10
+    pipe = IdentificationPipeline(g.robot(), g.param, params_std=g.params_std(), coupling=g.coupling)
+    q, v, a = g["q_big"].copy(), g["v_big"].copy(), g["a_big"].copy()
+    pipe.set_samples(q, v, a, g["tau"])
+    out = pipe.run()
+    assert out["idx_e"] == list(g["idx_e"])
+    # same pipeline object, same HBM buffers: overwrite the samples in place with a motion of the last three joints only
+    q2, v2, a2 = q.copy(), v.copy(), a.copy()
+    q2[:, :3] = 0.0
+    v2[:, :3] = 0.0
+    a2[:, :3] = 0.0
+    for d_arr, h in ((pipe.d_q, q2), (pipe.d_v, v2), (pipe.d_a, a2)):
+        h = np.ascontiguousarray(h)
+        lib.check(lib.load().figh_memcpy_h2d(d_arr.ptr, h.ctypes.data, h.nbytes))
+    out2 = pipe.run()
+    W2 = build_regressor_basic(g.robot(), q2, v2, a2, g.param)
+    idx_e2, params_r2 = get_index_eliminate(W2, g.params_std(), 1e-6)
+    assert out2["idx_e"] == idx_e2 and out2["params_r"] == params_r2
+    assert len(idx_e2) != len(g["idx_e"])
+    keep = [i for i in range(W2.shape[1]) if i not in set(idx_e2)]
+    assert out2["idx_base"] == list(get_baseIndex(np.ascontiguousarray(W2[:, keep]), params_r2))
+    out3 = pipe.run()
+    assert out3["idx_base"] == out2["idx_base"] and np.array_equal(out3["beta"], out2["beta"])
