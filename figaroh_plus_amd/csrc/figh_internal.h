@@ -83,6 +83,11 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
 // FIGH_ERR_UNSUPPORTED when the stack is too tall for one resident grid.
 int launch_tsqr_tree(const double *Rs, long count, int nc, int n_free, double tol, double *d_out, double *d_rows_out);
 
+// figh_tsqr_stream.hip: the same contract as launch_tsqr_tree, with the levels, the rank decision and the regrouped
+// factorisation software-pipelined (about nc column steps in total).  FIGH_ERR_UNSUPPORTED when the tree does not fit one
+// resident grid.
+int launch_tsqr_stream(const double *Rs, long count, int nc, int n_free, double tol, double *d_out, double *d_rows_out);
+
 #define FIGH_HIP(expr)                                                                          \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \

@@ -708,10 +708,18 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
 //             latency-bound, ~1 us per dependent column step;
 //   nc  > 80: the stack is a tall matrix again (fan-in 4 per level through the wide kernel; tiles inside a triangle
 //             start at their first non-zero column).
+// all merge levels (+ rank decision and regrouping when d_rows_out) in one launch: the pipelined tree if it fits one
+// resident grid, else the level-by-level tree; FIGH_ERR_UNSUPPORTED if neither does
+static int merge_one_launch(const double *Rs, long count, int nc, int n_free, double tol, double *d_out, double *d_rows_out) {
+    const int rc = launch_tsqr_stream(Rs, count, nc, n_free, tol, d_out, d_rows_out);
+    if (rc != FIGH_ERR_UNSUPPORTED) return rc;
+    return launch_tsqr_tree(Rs, count, nc, n_free, tol, d_out, d_rows_out);
+}
+
 static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out) {
     const size_t tri = sizeof(double) * (size_t)nc * nc;
     if (nc <= 80 && count > 1) {  // every level in one launch (figh_tsqr_tree.hip) when the stack fits one resident grid
-        const int rc = launch_tsqr_tree(Rs, count, nc, 0, 0.0, d_R_out, nullptr);
+        const int rc = merge_one_launch(Rs, count, nc, 0, 0.0, d_R_out, nullptr);
         if (rc != FIGH_ERR_UNSUPPORTED) return rc;
     }
     const double *cur = Rs;
@@ -994,7 +1002,7 @@ int figh_select_columns(const double *d_colsq, int ncols, double tol_e, int link
 
 // plain triangle -> rows of the regrouped factorisation in the original column order + the plain diagonal (see figh.h)
 static int reveal_triangle(const double *d_R, int nc, int n_free, double tol_qr, double *d_rows_out) {
-    if (nc <= 80) return launch_tsqr_tree(d_R, 0, nc, n_free, tol_qr, nullptr, d_rows_out);
+    if (nc <= 80) return merge_one_launch(d_R, 0, nc, n_free, tol_qr, nullptr, d_rows_out);
     int *perm = static_cast<int *>(workspace(sizeof(int) * (size_t)nc, 17));
     double *Rr = static_cast<double *>(workspace(sizeof(double) * (size_t)nc * nc, 18));
     if (!perm || !Rr) return FIGH_ERR_ALLOC;
@@ -1019,7 +1027,7 @@ static int reduce_stack(const double *d_Rs, long count, int nc, int n_free, doub
         return reveal_triangle(one, nc, n_free, tol_qr, d_out);
     }
     if (nc <= 80) {
-        const int rc = launch_tsqr_tree(d_Rs, count, nc, n_free, tol_qr, one, d_out);
+        const int rc = merge_one_launch(d_Rs, count, nc, n_free, tol_qr, one, d_out);
         if (rc != FIGH_ERR_UNSUPPORTED) return rc;
     }
     if (int rc = tsqr_reduce(d_Rs, count, nc, one)) return rc;
