@@ -68,36 +68,41 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
     double Rk[LIVE], d[LIVE];
 #pragma unroll
     for (int cc = 0; cc < LIVE; ++cc) Rk[cc] = S.Rl[rowoff + 16 * cc + S.lane_c];
+    // the diagonal entry R_kk straight from LDS (one address for the whole wave: a broadcast read on the LDS port)
+    // instead of a v_mov_b64_dpp of Rk[0] on the VALU (8 ticks)
+    double alpha = S.Rl[rowoff + KK];
     {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four chains: no back-to-back dependent DPP instructions
+        double s0 = 0.0, s1 = 0.0;  // two chains (the second wave of the SIMD covers the FMA latency): 2 movs + 1 add
 #pragma unroll
-        for (int i = 0; i < NR; i += 4) {
+        for (int i = 0; i < NR; i += 2) {
             fmac_bcast<KK>(s0, S.T[P][i], S.T[P][i]);
             fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P][i + 1]);
-            fmac_bcast<KK>(s2, S.T[P][i + 2], S.T[P][i + 2]);
-            fmac_bcast<KK>(s3, S.T[P][i + 3], S.T[P][i + 3]);
         }
-        d[0] = tsqr2_reduce<LDSRED>(S, (s0 + s1) + (s2 + s3));
+        d[0] = tsqr2_reduce<LDSRED>(S, s0 + s1);
     }
     // row k of the triangle is requested before the dot product and pinned here, so that the LDS latency is not
     // part of the dependent chain below (the compiler would otherwise sink the read below the sigma branch)
 #pragma unroll
     for (int cc = 0; cc < LIVE; ++cc) asm volatile("" : "+v"(Rk[cc]));
-    const double alpha = row_bcast<KK>(Rk[0]);   // identical in all lanes (kept in VGPRs: no SGPR round trip)
+    asm volatile("" : "+v"(alpha));
     const double sigma = row_bcast<KK>(d[0]);
     if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
     // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
-    // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds + Newton steps instead of the
-    // IEEE sqrt and two divisions
+    // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds (~2^-24) + ONE third-order step each
+    // (y (1 + e/2 + 3e^2/8), e = 1 - q y^2: error e^3; r (1 + e + e^2), e = 1 - d r) instead of two Newton steps:
+    // 5 + 3 dependent operations instead of 7 + 4
     const double q2 = fma(alpha, alpha, sigma);
-    const double hq = -0.5 * q2;
     double rs = __builtin_amdgcn_rsq(q2);
-    rs = rs * fma(hq * rs, rs, 1.5);
-    rs = rs * fma(hq * rs, rs, 1.5);
+    {
+        const double e = fma(-(q2 * rs), rs, 1.0);
+        rs = fma(rs, fma(e, 0.375, 0.5) * e, rs);
+    }
     const double dsum = fma(q2, rs, fabs(alpha));  // |alpha| + s
     double ri = __builtin_amdgcn_rcp(dsum);
-    ri = ri * fma(-dsum, ri, 2.0);
-    ri = ri * fma(-dsum, ri, 2.0);
+    {
+        const double e = fma(-dsum, ri, 1.0);
+        ri = fma(ri, fma(e, e, e), ri);
+    }
     const double inv = copysign(ri, alpha);
     const double tfac = dsum * rs;
 #pragma unroll

@@ -31,7 +31,26 @@
 
 namespace figh {
 
+#ifdef FIGH_ABLATION
+// in-kernel step profile of the ablation build (tools/stream_prof.py): s_memtime at five points of every column step of
+// wave 0 of workgroup 0, accumulated per point
+__device__ long long g_stream_prof[8];
+#define FIGH_PROF_MARK(i) \
+    if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); g_stream_prof[i] += now_ - prof_t; prof_t = now_; }
+#define FIGH_PROF_BEGIN long long prof_t = (long long)__builtin_readcyclecounter();
+#else
+#define FIGH_PROF_MARK(i)
+#define FIGH_PROF_BEGIN
+#endif
+
 constexpr unsigned long long kPoison = 0xFFFBADC0FFEE5EEDull;
+// how many column steps ahead a row is requested.  Measured (tools/merge_tree_bench.py, 2039 triangles of 50 columns):
+// depth 1 / 2 / 3 / 4 -> 107 / 117 / 124 / 129 us: a deeper request only adds lag per level, the step itself does not wait
+// for its loads
+#ifndef FIGH_STREAM_DEPTH
+#define FIGH_STREAM_DEPTH 1
+#endif
+constexpr int kDepth = FIGH_STREAM_DEPTH;
 
 struct StreamPlan {
     int nlevels;   // merge levels; 0: `in` already is the plain triangle (regrouping only)
@@ -121,11 +140,16 @@ __device__ __forceinline__ void stream_step(double (&T)[merge_tile_n(NCC, FANR)]
     constexpr int kpos = 16 * P + KK;
     constexpr int J = kpos / 8, OW = kpos % 8;  // slot and owner wave of the arriving position
     const int buf = kpos & 1;
-    // the next position's rows are requested one step ahead by the wave that owns them (its slot is not read before then)
-    if constexpr (kpos + 1 < 16 * NCC) {
-        if (c.wave == (kpos + 1) % 8) arrive_issue<kpos + 1, NCC, FANR>(T, c);
+    FIGH_PROF_BEGIN
+    // the rows of position kpos + kDepth are requested now by the wave that owns them (its slot is not read before then)
+    if constexpr (kpos + kDepth < 16 * NCC) {
+        if (c.wave == (kpos + kDepth) % 8) arrive_issue<kpos + kDepth, NCC, FANR>(T, c);
     }
-    if (c.wave == OW) arrive_validate<kpos, NCC, FANR>(T, c);
+    if (c.wave == OW) {
+        if (kpos - c.pad < kDepth) arrive_issue<kpos, NCC, FANR>(T, c);  // the first steps: nobody asked before
+        arrive_validate<kpos, NCC, FANR>(T, c);
+    }
+    FIGH_PROF_MARK(0)
     const bool own = c.wave <= OW;  // this wave's slot J has arrived (position wave + 8 J <= kpos)
     double a0[LIVE], a1[LIVE];
 #pragma unroll
@@ -154,25 +178,33 @@ __device__ __forceinline__ void stream_step(double (&T)[merge_tile_n(NCC, FANR)]
         const double dw = allreduce_rowgroups(a0[cc] + a1[cc]);
         if (c.lane_g == 0) pw[buf][c.wave][16 * (P + cc) + c.lane_c] = dw;
     }
+    FIGH_PROF_MARK(1)
     __syncthreads();
+    FIGH_PROF_MARK(2)
     // every wave sums the partials itself, in wave order: same bits everywhere.  Pivot chunk first: it feeds the
     // rsq chain, behind which the reads of the trailing chunks hide.
     double d[LIVE];
 #pragma unroll
     for (int cc = 0; cc < LIVE; ++cc) {
-        double s = pw[buf][0][16 * (P + cc) + c.lane_c];
+        double pp[NW];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) s += pw[buf][w][16 * (P + cc) + c.lane_c];
-        d[cc] = s;
+        for (int w = 0; w < NW; ++w) pp[w] = pw[buf][w][16 * (P + cc) + c.lane_c];
+        // fixed pairwise order (three dependent additions instead of seven)
+        d[cc] = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
         if (cc == 0) __builtin_amdgcn_sched_barrier(0);
     }
     const double sigma = row_bcast<KK>(d[0]);
-    const double hq = -0.5 * sigma;
     double rs = __builtin_amdgcn_rsq(sigma);
-    rs = rs * fma(hq * rs, rs, 1.5);
-    rs = rs * fma(hq * rs, rs, 1.5);
+    {   // one third-order step on the 2^-24 seed: y (1 + e/2 + 3 e^2 / 8), e = 1 - sigma y^2
+        const double e = fma(-(sigma * rs), rs, 1.0);
+        rs = fma(rs, fma(e, 0.375, 0.5) * e, rs);
+    }
     rs = sigma != 0.0 ? rs : 0.0;  // zero column: H = I and a row of zeros (which must still be published)
     const int k = kpos - c.pad;
+#ifdef FIGH_ABLATION
+    asm volatile("" : "+v"(rs));
+#endif
+    FIGH_PROF_MARK(3)
 #pragma unroll
     for (int cc = LIVE - 1; cc >= 0; --cc) {
         const double wj = d[cc] * rs;
@@ -192,17 +224,14 @@ __device__ __forceinline__ void stream_step(double (&T)[merge_tile_n(NCC, FANR)]
             if (c.plain) c.plain[(unsigned)(k * c.nc + col)] = val;
         }
     }
+    FIGH_PROF_MARK(4)
 }
 
 template <int P, int NCC, int FANR, int NW>
 __device__ __forceinline__ void stream_panels(double (&T)[merge_tile_n(NCC, FANR)], const MergeCtx<NCC, FANR> &c,
                                               double (*pw)[NW][16 * NCC]) {
-#define FIGH_QSTEP(KK)                                                          \
-    if (16 * P + KK >= c.pad) {                                                 \
-        if (16 * P + KK == c.pad && c.wave == (16 * P + KK) % 8)                \
-            arrive_issue<16 * P + KK, NCC, FANR>(T, c);                         \
-        stream_step<KK, P, NCC, FANR, NW>(T, c, pw);                            \
-    }
+#define FIGH_QSTEP(KK) \
+    if (16 * P + KK >= c.pad) stream_step<KK, P, NCC, FANR, NW>(T, c, pw);
     FIGH_QSTEP(0) FIGH_QSTEP(1) FIGH_QSTEP(2) FIGH_QSTEP(3) FIGH_QSTEP(4) FIGH_QSTEP(5) FIGH_QSTEP(6) FIGH_QSTEP(7)
     FIGH_QSTEP(8) FIGH_QSTEP(9) FIGH_QSTEP(10) FIGH_QSTEP(11) FIGH_QSTEP(12) FIGH_QSTEP(13) FIGH_QSTEP(14)
     FIGH_QSTEP(15)
@@ -240,12 +269,14 @@ __device__ __forceinline__ void solo_issue(double (&S)[NCC], const SoloCtx &c) {
 }
 
 template <int KK, int P, int NCC>
-__device__ __forceinline__ void solo_stream_step(double (&T)[solo_tile_n(NCC)], double (&S)[NCC], const SoloCtx &c) {
+__device__ __forceinline__ void solo_stream_step(double (&T)[solo_tile_n(NCC)], double (&SS)[kDepth][NCC], const SoloCtx &c) {
     using ST = SoloTile<NCC>;
     constexpr int LIVE = NCC - P;
     constexpr int kpos = 16 * P + KK;
     constexpr int RR = KK / 4, RG = KK % 4;  // register and row group of the arriving row inside row chunk P
-    // arrival of row kpos (requested one step ago)
+    // arrival of row kpos (requested kDepth steps ago into staging set kpos mod kDepth)
+    double (&S)[NCC] = SS[kpos % kDepth];
+    if (kpos - c.pad < kDepth) solo_issue<kpos, NCC>(S, c);  // the first steps: nobody asked before
     for (;;) {
         bool bad = false;
 #pragma unroll
@@ -265,7 +296,7 @@ __device__ __forceinline__ void solo_stream_step(double (&T)[solo_tile_n(NCC)], 
 #pragma unroll
     for (int cc = P; cc < NCC; ++cc)
         if (c.lane_g == RG) T[ST::ix(P, cc, RR)] = S[cc];
-    if constexpr (kpos + 1 < 16 * NCC) solo_issue<kpos + 1, NCC>(S, c);
+    if constexpr (kpos + kDepth < 16 * NCC) solo_issue<kpos + kDepth, NCC>(S, c);  // same staging set: it is free now
     // the diagonal entry of the plain triangle: lane (RG, KK) of the pivot chunk
     const double mine = T[ST::ix(P, P, RR)];
     const double dkk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), 16 * RG + KK),
@@ -287,10 +318,11 @@ __device__ __forceinline__ void solo_stream_step(double (&T)[solo_tile_n(NCC)], 
         d[cc] = allreduce_rowgroups(a0 + a1);
     }
     const double sigma = row_bcast<KK>(d[0]);
-    const double hq = -0.5 * sigma;
     double rs = __builtin_amdgcn_rsq(sigma);
-    rs = rs * fma(hq * rs, rs, 1.5);
-    rs = rs * fma(hq * rs, rs, 1.5);
+    {
+        const double e = fma(-(sigma * rs), rs, 1.0);
+        rs = fma(rs, fma(e, 0.375, 0.5) * e, rs);
+    }
     rs = sigma != 0.0 ? rs : 0.0;
     double *Rrow = c.rows_out + (long)k * c.nc - c.pad;
 #pragma unroll
@@ -308,12 +340,9 @@ __device__ __forceinline__ void solo_stream_step(double (&T)[solo_tile_n(NCC)], 
 }
 
 template <int P, int NCC>
-__device__ __forceinline__ void solo_stream_panels(double (&T)[solo_tile_n(NCC)], double (&S)[NCC], const SoloCtx &c) {
-#define FIGH_RSTEP(KK)                                                   \
-    if (16 * P + KK >= c.pad) {                                          \
-        if (16 * P + KK == c.pad) solo_issue<16 * P + KK, NCC>(S, c);    \
-        solo_stream_step<KK, P, NCC>(T, S, c);                           \
-    }
+__device__ __forceinline__ void solo_stream_panels(double (&T)[solo_tile_n(NCC)], double (&S)[kDepth][NCC], const SoloCtx &c) {
+#define FIGH_RSTEP(KK) \
+    if (16 * P + KK >= c.pad) solo_stream_step<KK, P, NCC>(T, S, c);
     FIGH_RSTEP(0) FIGH_RSTEP(1) FIGH_RSTEP(2) FIGH_RSTEP(3) FIGH_RSTEP(4) FIGH_RSTEP(5) FIGH_RSTEP(6) FIGH_RSTEP(7)
     FIGH_RSTEP(8) FIGH_RSTEP(9) FIGH_RSTEP(10) FIGH_RSTEP(11) FIGH_RSTEP(12) FIGH_RSTEP(13) FIGH_RSTEP(14)
     FIGH_RSTEP(15)
@@ -395,11 +424,13 @@ __global__ __launch_bounds__(64 * NW) void tsqr_stream_kernel(const double *in, 
         c.R = rb;
         c.repoison = rb;
     }
-    double T[solo_tile_n(NCC)], S[NCC];
+    double T[solo_tile_n(NCC)], S[kDepth][NCC];
 #pragma unroll
     for (int e = 0; e < solo_tile_n(NCC); ++e) T[e] = 0.0;
 #pragma unroll
-    for (int e = 0; e < NCC; ++e) S[e] = 0.0;
+    for (int dd = 0; dd < kDepth; ++dd)
+#pragma unroll
+        for (int e = 0; e < NCC; ++e) S[dd][e] = 0.0;
     solo_stream_panels<0, NCC>(T, S, c);
 }
 
@@ -465,3 +496,12 @@ int launch_tsqr_stream(const double *Rs, long count, int nc, int n_free, double 
 }
 
 }  // namespace figh
+
+#ifdef FIGH_ABLATION
+extern "C" int figh_ab_stream_prof(long long *h_out, int reset) {
+    long long zero[8] = {0};
+    if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(figh::g_stream_prof), sizeof(zero)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(figh::g_stream_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -1,6 +1,6 @@
-# same-box A/B of two library builds on a BASELINE config: ab/libfigh_prev.so against the tree's libfigh.so
-cfg=${1:-cfg4}
-for rep in 1 2; do
-  echo "== prev"; FIGH_LIB_PATH=$PWD/ab/libfigh_prev.so python tools/step_profile.py $cfg 4 2>&1 | grep "ms per step\|kernel averages"
-  echo "== new";  python tools/step_profile.py $cfg 4 2>&1 | grep "ms per step\|kernel averages"
+# same-box A/B: ab/libfigh_prev.so (tools/build_prev.sh) against the in-tree library, three alternations
+cd $GRAFT_REPO_ROOT
+for rep in 1 2 3; do
+  FIGH_LIB_PATH=$PWD/ab/libfigh_prev.so python tools/ab_step.py
+  python tools/ab_step.py
 done
