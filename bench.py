@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--placement-trials", type=int, default=4,
+                    help="set-up (untimed): candidate allocations of W among which the one K1 writes fastest is kept "
+                         "(IdentificationPipeline.placement_trials; 1 = take the first)")
     ap.add_argument("--host-wait", default=None, choices=["spin", "block"],
                     help="how the host waits for the GPU: spin (default for one GPU) or block = interrupt-driven (default "
                          "for several ranks on a node: spinning ranks can exhaust a container's CPU quota)")
@@ -206,15 +209,16 @@ def main():
     else:
         q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
     pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
-                                  chunk_samples=chunk)
+                                  chunk_samples=chunk, placement_trials=args.placement_trials)
     pipe.set_samples(q, v, a)
     phi_ref = np.array([float(x) for x in meta["phi_ref_raw"]])
     pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config == "cfg2" else 0.0, seed=rank)
     del q, v, a
 
     out = None
-    # live HIP-event timing of the dominant kernels on the library stream (level 1: four event records per pass),
-    # switched on during warm-up already so that the event pool exists before the timed region
+    # live HIP-event timing of the dominant kernels on the library stream (level 1: the event pair of K1 and of the TSQR
+    # level 0 is stamped by their own dispatch packets, hipExtLaunchKernelGGL -- no extra packets in the queue), switched
+    # on during warm-up already so that the event pool exists before the timed region
     _lib.profile_enable(True, level=1)
     for _ in range(args.warmup):
         out = pipe.run()
@@ -252,7 +256,7 @@ def main():
     _lib.profile_reset()
     for _ in range(2):
         pipe.run()
-    for name in ("tsqr_reduce", "tsqr_small", "gather_cols", "rccl_allgather", "rccl_allreduce"):
+    for name in ("tsqr_tree", "tsqr_reduce", "select_columns", "rccl_allgather", "rccl_allreduce"):
         cnt, ms = _lib.profile_get(name)
         if cnt:
             kern[name] = {"launches_per_step": cnt / 2.0, "avg_ms": ms / cnt, "timed_region": False}
@@ -349,6 +353,7 @@ def main():
                 "rank0_seconds": dt_rank, "max_rank_seconds": dt,
                 "device": _lib.device_info()["name"], "result_matches_reference": bool(ok),
                 "figh_env": "none set (checked)", "host_wait": host_wait,
+                "w_placement": pipe.placement_report or {"trials": 1},
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
             "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},

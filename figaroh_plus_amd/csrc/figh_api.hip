@@ -72,7 +72,10 @@ void *workspace(size_t bytes, int slot) {
     return g_ws[slot];
 }
 
-ProfileScope::ProfileScope(const char *name) : name_(name) {
+static LaunchEvents g_launch_events;
+static bool g_launch_events_taken = false;
+
+ProfileScope::ProfileScope(const char *name, bool at_launch) : name_(name), at_launch_(at_launch) {
     if (!g_profile) return;
     if (g_profile == 1 && std::strcmp(name, "regressor_chain") != 0 && std::strcmp(name, "regressor_tree") != 0 &&
         std::strcmp(name, "tsqr") != 0)
@@ -80,13 +83,36 @@ ProfileScope::ProfileScope(const char *name) : name_(name) {
     e0_ = acquire_event();
     e1_ = acquire_event();
     if (!e0_ || !e1_) return;
-    (void)hipEventRecord(e0_, g_stream);
+    if (at_launch_) {
+        g_launch_events.start = e0_;
+        g_launch_events.stop = e1_;
+        g_launch_events_taken = false;
+    } else {
+        (void)hipEventRecord(e0_, g_stream);
+    }
 }
 
 ProfileScope::~ProfileScope() {
     if (!e0_ || !e1_) return;
-    (void)hipEventRecord(e1_, g_stream);
+    if (at_launch_) {
+        const bool used = g_launch_events_taken && g_launch_events.start == nullptr;
+        g_launch_events = LaunchEvents();
+        if (!used) {  // nothing was launched through FIGH_LAUNCH_TIMED inside the scope
+            g_event_pool.push_back(e0_);
+            g_event_pool.push_back(e1_);
+            return;
+        }
+    } else {
+        (void)hipEventRecord(e1_, g_stream);
+    }
     g_prof[name_].pending.emplace_back(e0_, e1_);
+}
+
+LaunchEvents take_launch_events() {
+    const LaunchEvents ev = g_launch_events;
+    if (ev.start) g_launch_events_taken = true;
+    g_launch_events = LaunchEvents();
+    return ev;
 }
 
 static void drain_profile() {

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -43,13 +44,30 @@ void set_error(const std::string &msg);
 hipStream_t stream();
 int ensure_device();
 
-// per-kernel-family hipEvent timing (figh_profile_*)
+// per-kernel-family hipEvent timing (figh_profile_*).  Two forms:
+//   ProfileScope s("name")           events recorded on the stream around everything launched inside the scope;
+//   ProfileScope s("name", true)     the dominant kernels: the event pair is handed to the ONE launch inside the scope that
+//                                    goes through FIGH_LAUNCH_TIMED (hipExtLaunchKernelGGL stamps them from the dispatch
+//                                    packet itself).  Event records on the stream are barrier packets of their own: four
+//                                    of them per pass cost 0.1 ms of a 1.85 ms UR10 step once the pass had no host round
+//                                    trips left to hide them behind.
 struct ProfileScope {
-    explicit ProfileScope(const char *name);
+    explicit ProfileScope(const char *name, bool at_launch = false);
     ~ProfileScope();
     const char *name_;
     hipEvent_t e0_ = nullptr, e1_ = nullptr;
+    bool at_launch_ = false;
 };
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchEvents take_launch_events();  // the pair of the innermost at_launch scope (nullptr, nullptr when none / not profiling)
+
+#define FIGH_LAUNCH_TIMED(kernel, grid, block, lds, ...)                                                        \
+    do {                                                                                                        \
+        const figh::LaunchEvents ev_ = figh::take_launch_events();                                              \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, figh::stream(), ev_.start, ev_.stop, 0, __VA_ARGS__);    \
+    } while (0)
 
 // scratch buffer owned by the library, grown on demand (device)
 void *workspace(size_t bytes, int slot);

@@ -699,11 +699,11 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
     if (!th) return FIGH_ERR_ALLOC;
     dim3 grid((unsigned)nw), block(64);
     if (nc <= 64)
-        hipLaunchKernelGGL((tsqr2_kernel<4, 4, true>), grid, block, tsqr2_lds_bytes(4, nc), stream(), W, rows, ldw, col_idx,
-                           n, tau, d_blkw, rows_per_blk, Rws_out, nc, th);
+        FIGH_LAUNCH_TIMED((tsqr2_kernel<4, 4, true>), grid, block, tsqr2_lds_bytes(4, nc), W, rows, ldw, col_idx, n, tau,
+                          d_blkw, rows_per_blk, Rws_out, nc, th);
     else
-        hipLaunchKernelGGL((tsqr2_kernel<5, 4, false>), grid, block, tsqr2_lds_bytes(5, nc), stream(), W, rows, ldw,
-                           col_idx, n, tau, d_blkw, rows_per_blk, Rws_out, nc, th);
+        FIGH_LAUNCH_TIMED((tsqr2_kernel<5, 4, false>), grid, block, tsqr2_lds_bytes(5, nc), W, rows, ldw, col_idx, n, tau,
+                          d_blkw, rows_per_blk, Rws_out, nc, th);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }
@@ -909,7 +909,7 @@ int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t
     g_tile_hint = nullptr;
     long nw = 0;
     {
-        ProfileScope scope(rows >= 65536 ? "tsqr" : "tsqr_small");
+        ProfileScope scope(rows >= 65536 ? "tsqr" : "tsqr_small", true);
         if (int rc = tsqr_level(d_W, rows, ldw, d_col_idx, n, d_tau, d_blkw, rows_per_blk, nc, target, Rws, &nw, hint))
             return rc;
     }

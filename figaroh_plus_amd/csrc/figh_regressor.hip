@@ -23,6 +23,8 @@
 //
 // All arithmetic is fp64.  6-vectors are (linear, angular).
 #include <cmath>
+#include <type_traits>
+#include <cstdlib>
 
 #include "figh_internal.h"
 #include "figh_spatial.h"
@@ -30,6 +32,10 @@
 namespace figh {
 
 // ---------------------------------------------------------------------------------------------- chain kernel
+#ifdef FIGH_ABLATION
+__device__ int g_chain_hotin = 0;
+#endif
+
 template <int NJ>
 struct ChainParams {
     double axis[NJ][3];
@@ -69,11 +75,28 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
 #pragma unroll
     for (int j = 0; j < NJ; ++j) csA[j] = csB[j] = 0.0;
 
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // The tile body, in two instantiations.  FAST: full tile, packed rows, 16-byte stores -- straight-line code with exactly
+    // NJ * CH stores, used by the main loop below.  Otherwise: any tile (ragged last tile, padded leading dimension).
+    double pq[NJ], pqd[NJ], pqdd[NJ];  // this tile's inputs (requested one tile ahead in the main loop)
+    auto fetch_inputs = [&](const long tile) {
+        const long j0 = tile * 64;
+        const int nv = (int)((N - j0) < 64 ? (N - j0) : 64);
+#ifdef FIGH_ABLATION
+        const long is = g_chain_hotin ? (lane < nv ? lane : nv - 1) : j0 + (lane < nv ? lane : nv - 1);
+#else
+        const long is = j0 + (lane < nv ? lane : nv - 1);
+#endif
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            pq[k] = q[is * NJ + k];
+            pqd[k] = v[is * NJ + k];
+            pqdd[k] = a[is * NJ + k];
+        }
+    };
+    auto tile_body = [&](auto FAST_T, const long t, const long tnext) {
+        constexpr bool FAST = decltype(FAST_T)::value;
         const long i0 = t * 64;
-        const int nvalid = (int)((N - i0) < 64 ? (N - i0) : 64);
-        const long i = i0 + (lane < nvalid ? lane : nvalid - 1);
-
+        const int nvalid = FAST ? 64 : (int)((N - i0) < 64 ? (N - i0) : 64);
         double qd[NJ], qdd[NJ];
         double R[NJ][9];
         double acc[NJ][3], dw[NJ][3], w[NJ][3];
@@ -81,9 +104,9 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
             double vl[3] = {0, 0, 0}, om[3] = {0, 0, 0}, al[3] = {-P.g[0], -P.g[1], -P.g[2]}, da[3] = {0, 0, 0};
 #pragma unroll
             for (int k = 0; k < NJ; ++k) {
-                const double qk = q[i * NJ + k];
-                qd[k] = v[i * NJ + k];
-                qdd[k] = a[i * NJ + k];
+                const double qk = pq[k];
+                qd[k] = pqd[k];
+                qdd[k] = pqdd[k];
                 double s, c;
                 sincos(qk, &s, &c);
                 double Rj[9];
@@ -124,6 +147,7 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
             }
         }
 
+        if constexpr (FAST) fetch_inputs(tnext);  // (pq / pqd / pqdd have been consumed by the recursion above)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             // ---- this lane's row (j, i): 14 columns per link
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
             double *dst = W + ((long)j * N + i0) * ldw;
             bool streamed = false;
             if constexpr (G::VEC == 2) {
-                if (vec_ok && nvalid == 64 && ldw == NC) {
+                if (FAST || (vec_ok && nvalid == 64 && ldw == NC)) {
                     // full tile, packed rows: the 64 rows are one contiguous run of 64 NC doubles in W.  Chunk id (16 B)
                     // sits at byte 16 id in W and at 16 (id + r) in the padded tile, r = id / CH by a magic multiply
                     // (exact for id < 64 CH <= 4096): 5 instructions per chunk instead of a division and two 64-bit
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
                     streamed = true;
                 }
             }
-            if (streamed) {
+            if (FAST || streamed) {
             } else if (vec_ok) {
                 constexpr int CH = G::CH, VEC = G::VEC;
                 const int total = nvalid * CH;
@@ -269,6 +293,33 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
             }
             __syncthreads();
         }
+
+    };
+    // Main loop over the full tiles when W is packed and aligned.  The inputs of the NEXT tile are requested before this
+    // tile's NJ * CH stores.  Loads and stores retire through one in-order counter (vmcnt): a load issued BEHIND the stores
+    // can only be waited for together with all of them, and the wave used to sit at the top of every tile until HBM had
+    // acknowledged its last store and then delivered q, v, a (with the inputs served from cache the kernel is 0.065 ms
+    // faster, tools/k1_alloc_probe.py with FIGH_CHAIN_HOTIN).  Requested up front they are older than the stores, and
+    // because this loop's body has a fixed number of stores on every path the compiler's wait for them is vmcnt(63):
+    // all but the youngest 63 operations -- i.e. the stores of the last row block stay in flight.
+    long t = blockIdx.x;
+    if constexpr (G::VEC == 2) {
+        const long nfast = (vec_ok && ldw == NC) ? N / 64 : 0;
+        if (t < nfast) {
+            fetch_inputs(t);
+            // waited for here, outside the loop: a request still pending at the loop header would put a full wait at the
+            // top of every iteration
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) asm volatile("" : "+v"(pq[k]), "+v"(pqd[k]), "+v"(pqdd[k]));
+        }
+        for (; t < nfast; t += gridDim.x) {
+            const long tn = t + gridDim.x;
+            tile_body(std::true_type{}, t, tn < nfast ? tn : t);
+        }
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        fetch_inputs(t);
+        tile_body(std::false_type{}, t, -1);
     }
     if constexpr (COLSQ) {
         static_assert(NC <= 128, "colsq ownership covers two columns per lane");
@@ -342,17 +393,23 @@ static int launch_chain(const figh_model_s *m, int flags, long N, const double *
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     const int vec_ok = (ldw % G::VEC == 0) && ((reinterpret_cast<uintptr_t>(W) % (8 * G::VEC)) == 0);
-    ProfileScope scope("regressor_chain");
+#ifdef FIGH_ABLATION
+    {
+        const int hot = getenv("FIGH_CHAIN_HOTIN") != nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_hotin), &hot, sizeof(int));
+    }
+#endif
+    ProfileScope scope("regressor_chain", true);
     if (d_colsq) {
         double *part = static_cast<double *>(workspace(sizeof(double) * grid * G::NC, 0));
         if (!part) return FIGH_ERR_ALLOC;
-        hipLaunchKernelGGL((regressor_chain_kernel<NJ, TX40, true>), dim3((unsigned)grid), dim3(64), lds, stream(), P,
-                           flags, N, q, v, a, W, ldw, vec_ok, part);
+        FIGH_LAUNCH_TIMED((regressor_chain_kernel<NJ, TX40, true>), dim3((unsigned)grid), dim3(64), lds, P, flags, N, q, v, a,
+                          W, ldw, vec_ok, part);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(G::NC), dim3(256), 0, stream(), part, (int)grid,
                            G::NC, d_colsq);
     } else {
-        hipLaunchKernelGGL((regressor_chain_kernel<NJ, TX40, false>), dim3((unsigned)grid), dim3(64), lds, stream(), P,
-                           flags, N, q, v, a, W, ldw, vec_ok, nullptr);
+        FIGH_LAUNCH_TIMED((regressor_chain_kernel<NJ, TX40, false>), dim3((unsigned)grid), dim3(64), lds, P, flags, N, q, v,
+                          a, W, ldw, vec_ok, (double *)nullptr);
     }
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;

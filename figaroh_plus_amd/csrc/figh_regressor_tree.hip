@@ -688,10 +688,10 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
         part = static_cast<double *>(workspace(sizeof(double) * grid * ncols_int, 0));
         if (!part) return FIGH_ERR_ALLOC;
     }
-    ProfileScope scope("regressor_tree");
-#define FIGH_TAPE_LAUNCH(LS, E, V2, ST, C)                                                                             \
-    hipLaunchKernelGGL((regressor_tape_kernel<LS, E, V2, ST, C>), dim3((unsigned)grid), dim3(64), lds, stream(), m->dev, \
-                       tp.dev, tp.n, flags, N, q, v, a, W, ldw, ncols_int, part)
+    ProfileScope scope("regressor_tree", true);
+#define FIGH_TAPE_LAUNCH(LS, E, V2, ST, C)                                                                         \
+    FIGH_LAUNCH_TIMED((regressor_tape_kernel<LS, E, V2, ST, C>), dim3((unsigned)grid), dim3(64), lds, m->dev, tp.dev, \
+                      tp.n, flags, N, q, v, a, W, ldw, ncols_int, part)
 #define FIGH_TAPE_MODES(LS, E)                                      \
     do {                                                            \
         if (!store) FIGH_TAPE_LAUNCH(LS, E, true, false, true);     \

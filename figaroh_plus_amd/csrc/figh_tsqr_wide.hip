@@ -836,10 +836,10 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
     }
 #endif
     const bool ok = wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
-        hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
-                                           decltype(WPE)::value, decltype(LDSC)::value>),
-                           dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, stream(), W, rows, ldw, col_idx, n, tau,
-                           d_blkw, rows_per_blk, Rblk, Rws_out, nc, prof);
+        FIGH_LAUNCH_TIMED((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
+                                          decltype(WPE)::value, decltype(LDSC)::value>),
+                          dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, W, rows, ldw, col_idx, n, tau, d_blkw,
+                          rows_per_blk, Rblk, Rws_out, nc, prof);
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");

@@ -54,12 +54,18 @@ def _dtrtri(R1):
 
 class IdentificationPipeline:
     def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
-                 chunk_samples=None):
+                 chunk_samples=None, placement_trials=1):
         """``chunk_samples``: when the stacked regressor of all N samples does not fit HBM (human model at 1e7
         samples: 269 GB) the samples are processed in chunks of this size -- pass 1 accumulates diag(W^T W), pass 2
         rebuilds each chunk's W (recomputing is far cheaper than storing), factors it and stacks the triangles,
         which ``figh_tsqr_merge`` reduces.  Results are those of the one-shot pass (R is row-order independent)."""
         self.chunk_samples = chunk_samples
+        # placement_trials > 1: when W is allocated, that many candidate buffers are allocated side by side, the regressor
+        # kernel is timed on each and the fastest one is kept (set-up cost: a few passes of K1).  The time K1 needs for the
+        # same 4 GB depends on the physical pages behind them -- 0.68 or 0.82 ms per allocation, hipMemset moves with it
+        # (0.60 / 0.63 ms), measured with tools/k1_alloc_probe.py -- and the allocator offers no handle on that.
+        self.placement_trials = max(1, int(placement_trials))
+        self.placement_report = None
         self.robot, self.param, self.coupling = robot, param, coupling
         self.tol_e, self.tol_qr = tol_e, tol_qr
         self.params_std = params_std if params_std is not None else robot.get_standard_parameters(param)
@@ -194,12 +200,9 @@ class IdentificationPipeline:
             # Trees: the link-padded layout of figh_regressor_build_padded -- 16 columns per link, every (row, link)
             # segment one 128-byte line -- which K1' writes at about twice the rate; the TSQR takes a column list anyway.
             self._padded = not (handle.is_chain() and mode == _lib.MODE_JOINT_TORQUE) and not self.coupling
-            if self._padded:
-                self.W = GpuMatrix.empty(rows_per_sample * self.N, 16 * (self.robot.model.njoints - 1))
-                self.W.ref_cols = ncols
-            else:
-                self.W = GpuMatrix.empty(rows_per_sample * self.N, ncols)
-                self.W.ref_cols = ncols
+            wcols = 16 * (self.robot.model.njoints - 1) if self._padded else ncols
+            self.W = self._place_W(rows_per_sample * self.N, wcols, handle, mode, flags, ft_mask)
+            self.W.ref_cols = ncols
             cap = ncols + 1
             # one buffer for everything that returns to the host: [colsq (ncols f64) | sel (2 + 2 ncols i32) | rows ((cap+1) cap f64)]
             self._sel_words = (2 + 2 * ncols + 1) // 2
@@ -258,6 +261,35 @@ class IdentificationPipeline:
             self._kept_cache = (kept_mask.copy(), list(idx_e), list(params_r))
         rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
         return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+
+    def _place_W(self, rows, cols, handle, mode, flags, ft_mask):
+        """Allocate W; with ``placement_trials`` > 1 keep the candidate allocation on which K1 runs fastest."""
+        import time
+        nbytes = rows * cols * 8
+        trials = self.placement_trials
+        if trials > 1:
+            trials = max(1, min(trials, int(0.5 * _lib.device_info()["hbm_bytes"] // max(nbytes, 1))))
+        if trials <= 1:
+            return GpuMatrix.empty(rows, cols)
+        d_cs = _lib.DeviceArray((cols,), np.float64)
+        build = _lib.regressor_build_padded if self._padded else _lib.regressor_build
+        cands, times = [], []
+        for _ in range(trials):  # all candidates are alive at once: a freed block would simply be handed out again
+            W = GpuMatrix.empty(rows, cols)
+            for rep in range(4):
+                if rep == 1:
+                    _lib.synchronize()
+                    t0 = time.perf_counter()
+                build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_cs)
+            _lib.synchronize()
+            cands.append(W)
+            times.append((time.perf_counter() - t0) / 3)
+        best = int(np.argmin(times))
+        for i, W in enumerate(cands):
+            if i != best:
+                W.buf.free()
+        self.placement_report = {"trials": trials, "k1_ms": [round(1e3 * t, 4) for t in times], "kept": best}
+        return cands[best]
 
     def _tail(self, d_stack, count, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
         """Stack of plain triangles in HBM (one per rank) -> results: reduction, rank decision and regrouped factorisation
