@@ -174,6 +174,37 @@ def rnea(flat, q, v, a):
     return tau
 
 
+def rnea_with_parameters(flat, q, v, a, pi):
+    """Recursive Newton-Euler with the inertial parameters given explicitly: ``pi`` is (njoints-1, 10) in Pinocchio's order
+    [m, m c, I_O(xx xy yy xz yz zz)] (first moment and inertia about the joint origin).  tau is linear in pi, so
+    ``rnea_with_parameters(.., e_(i,p))`` is column 10 (i-1) + p of the joint-torque regressor: the column-by-column pin of
+    ``joint_torque_regressor`` (tests/test_oracle.py).  Nothing here touches ``body_regressor``."""
+    n = int(flat["njoints"])
+    liMi, S, V, A = forward_pass(flat, q, v, a)
+    f = [np.zeros(6) for _ in range(n)]
+    for i in range(1, n):
+        m, h = pi[i - 1][0], np.asarray(pi[i - 1][1:4], dtype=float)
+        xx, xy, yy, xz, yz, zz = pi[i - 1][4:]
+        Io = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+        I6 = np.zeros((6, 6))
+        I6[:3, :3] = m * np.eye(3)
+        I6[:3, 3:] = -skew(h)
+        I6[3:, :3] = skew(h)
+        I6[3:, 3:] = Io
+        mom = I6 @ V[i]
+        vl, w = V[i][:3], V[i][3:]
+        f[i] = I6 @ A[i] + np.concatenate([np.cross(w, mom[:3]), np.cross(w, mom[3:]) + np.cross(vl, mom[:3])])
+    tau = np.zeros(int(flat["nv"]))
+    for i in range(n - 1, 0, -1):
+        iv, nvi = int(flat["idx_v"][i]), _nv_of(flat, i)
+        tau[iv:iv + nvi] = S[i].T @ f[i]
+        R, p = liMi[i]
+        lin = R @ f[i][:3]
+        par = int(flat["parents"][i])
+        f[par] = f[par] + np.concatenate([lin, R @ f[i][3:] + np.cross(p, lin)])
+    return tau
+
+
 def dynamic_parameters(flat):
     """Pinocchio-ordered [m, mc, Ixx Ixy Iyy Ixz Iyz Izz] (about the joint origin), joints 1..n-1."""
     out = []

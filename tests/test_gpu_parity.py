@@ -1190,3 +1190,41 @@ def test_pipeline_recovers_when_the_kept_set_changes(lib, golden_ur10):
     assert out2["idx_base"] == list(get_baseIndex(np.ascontiguousarray(W2[:, keep]), params_r2))
     out3 = pipe.run()
     assert out3["idx_base"] == out2["idx_base"] and np.array_equal(out3["beta"], out2["beta"])
+
+
+@pytest.mark.parametrize("freeflyer", [False, True])
+def test_handwritten_robot_against_first_principles(lib, tmp_path, freeflyer):
+    """The HIP regressor (tape kernel: branches, continuous / revolute / prismatic joints, merged fixed link, free-flyer
+    wrench rows) behind build_regressor_basic + Robot.get_standard_parameters against tests/indep_dynamics.py -- subtree
+    momenta differentiated numerically, no spatial algebra -- on 45 instances of a hand-written robot whose inertial data
+    span every parameter: W(q, v, a) . phi_std == tau for all of them pins every column of the device's W on physics,
+    with the product's own URDF loader in the loop."""
+    import indep_dynamics as idyn
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic
+    from figaroh_plus_amd.tools.robot import Robot
+    param = {"is_joint_torques": not freeflyer, "is_external_wrench": freeflyer, "force_torque": ["All"],
+             "has_friction": False, "has_actuator_inertia": False, "has_joint_offset": False}
+    rng = np.random.default_rng(21 + int(freeflyer))
+    N = 6
+    states = [idyn.sample_state(rng, freeflyer) for _ in range(N)]
+    q, v, a = (np.array([s[i] for s in states]) for i in range(3))
+    W0, PHI, TAU = None, [], []
+    for k in range(45):
+        ine = idyn.random_inertials(rng)
+        path = os.path.join(str(tmp_path), "b3_%d.urdf" % k)
+        with open(path, "w") as f:
+            f.write(idyn.urdf_text(ine))
+        robot = Robot(path, isFext=freeflyer)
+        if W0 is None:
+            W0 = build_regressor_basic(robot, q, v, a, param)  # kinematics only: the same for every instance
+        PHI.append(np.array(list(robot.get_standard_parameters(param).values()), dtype=float))
+        tau = np.array([idyn.generalised_forces(ine, *s, freeflyer) for s in states])  # N x nv
+        TAU.append((tau[:, :6] if freeflyer else tau).T.reshape(-1))                    # rows c * N + i, as W
+    PHI, TAU = np.array(PHI), np.array(TAU)
+    inertial = [c for c in range(W0.shape[1]) if c % 14 < 10]
+    assert np.linalg.matrix_rank(PHI[:, inertial]) == len(inertial)
+    assert not W0[:, [c for c in range(W0.shape[1]) if c % 14 >= 10]].any()
+    err = np.abs(PHI @ W0.T - TAU).max()
+    assert err <= 2e-7 * np.abs(TAU).max(), err
+    Wrec = np.linalg.lstsq(PHI[:, inertial], TAU, rcond=None)[0].T
+    assert np.abs(Wrec - W0[:, inertial]).max() <= 1e-5 * np.abs(W0).max()
