@@ -31,6 +31,7 @@ SIGNATURES = {
     "figh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "figh_device_set": (C.c_int, [C.c_int]),
     "figh_host_wait_mode": (C.c_int, [C.c_int]),
+    "figh_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "figh_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "figh_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "figh_free": (C.c_int, [C.c_void_p]),

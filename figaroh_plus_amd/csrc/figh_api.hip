@@ -50,6 +50,17 @@ int ensure_device() {
                   "); libfigh has no CPU path");
         return FIGH_ERR_NO_DEVICE;
     }
+    if (g_blocking_wait) {
+        // figh_host_wait_mode(1) without figh_device_set: the flag must precede the creation of the device's context.  A
+        // process that already has one (another library initialised HIP first) keeps its mode -- say so instead of
+        // silently spinning
+        const hipError_t fe = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        if (fe != hipSuccess) {
+            (void)hipGetLastError();
+            std::fprintf(stderr, "libfigh: interrupt-driven host waits were requested but the device context already "
+                                 "exists (%s); the host keeps spinning\n", hipGetErrorString(fe));
+        }
+    }
     FIGH_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     g_ready = true;
     return FIGH_OK;
@@ -152,12 +163,17 @@ int figh_device_count(int *count) {
 int figh_device_set(int device) {
     FIGH_REQUIRE(!g_ready, "figh_device_set must be called before any other device call");
     FIGH_HIP(hipSetDevice(device));
-    if (g_blocking_wait) {
-        // must precede the creation of the device's context; a process that already has one keeps its mode
-        const hipError_t e = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
-        if (e != hipSuccess) (void)hipGetLastError();
+    return ensure_device();  // (applies the host wait mode before the context is created)
+}
+
+int figh_device_pci_bus_id(int device, char *out, int out_len) {
+    FIGH_REQUIRE(out && out_len >= 16, "figh_device_pci_bus_id: buffer of at least 16 bytes");
+    hipError_t e = hipDeviceGetPCIBusId(out, out_len, device);  // creates no context
+    if (e != hipSuccess) {
+        set_error(std::string("hipDeviceGetPCIBusId: ") + hipGetErrorString(e));
+        return FIGH_ERR_NO_DEVICE;
     }
-    return ensure_device();
+    return FIGH_OK;
 }
 
 int figh_host_wait_mode(int blocking) {

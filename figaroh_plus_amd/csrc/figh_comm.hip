@@ -86,7 +86,7 @@ int figh_comm_init(int nranks, int rank, const void *h_id128) {
     FIGH_REQUIRE(h_id128 && nranks >= 1 && rank >= 0 && rank < nranks, "bad communicator arguments");
     FIGH_REQUIRE(!g_comm, "communicator already initialised");
     if (int rc = ensure_device()) return rc;
-    if (int rc = load_rccl()) return rc;
+    if (load_rccl()) return FIGH_ERR_UNSUPPORTED;  // (FIGH_ERR_COMM is reserved for what the rendezvous itself reports)
     UniqueId id;
     std::memcpy(&id, h_id128, sizeof(id));
     if (int rc = check(p_init(&g_comm, nranks, id, rank), "ncclCommInitRank")) return rc;

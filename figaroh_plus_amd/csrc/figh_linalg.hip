@@ -869,6 +869,9 @@ int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t
     const int nc = n + (d_tau ? 1 : 0);
     FIGH_REQUIRE(nc <= 512, "figh_tsqr: more than 512 columns not supported yet");
     FIGH_REQUIRE(ldw < (1L << 22), "figh_tsqr: leading dimension must be below 2^22 elements");
+    // the blocked kernel addresses a tile of up to 96 rows through one buffer descriptor whose size field holds 2^31 - 1
+    // bytes: 96 * ldw * 8 must stay below that, or rows of a full tile would be range-checked to zero
+    FIGH_REQUIRE(nc <= 80 || ldw < (1L << 21), "figh_tsqr: more than 80 columns need a leading dimension below 2^21 elements");
     if (int rc = ensure_device()) return rc;
     const double *d_blkw = nullptr;
     long rows_per_blk = 1;

@@ -29,6 +29,8 @@ def shard_range(n_total, rank, world_size):
 class TorchExchange:
     """Exchange through an initialised ``torch.distributed`` process group, staging through the host."""
 
+    collective = True
+
     def __init__(self, group=None):
         import torch.distributed as dist
 
@@ -81,6 +83,8 @@ class TorchExchange:
 
 class RcclExchange:
     """Exchange on device buffers with RCCL over xGMI (``figh_comm_*``)."""
+
+    collective = True
 
     def __init__(self, world_size, rank, ident):
         """``ident``: rank 0's 128-byte ncclUniqueId (see :func:`rccl_unique_id`), already shipped to this rank.
@@ -147,8 +151,11 @@ def exchange_from_env(prefer="rccl", device_key=None):
        ``(hostname, LOCAL_RANK)``); the outcomes are all-gathered over the gloo control plane;
     2. only if EVERY rank passed and no two ranks share a device (RCCL needs one GPU per rank) does rank 0 create the
        unique id; the id broadcast is executed by every rank in either case (an empty payload = "no RCCL");
-    3. all ranks call ``ncclCommInitRank``.  A failure from here on is not recoverable collectively: the exception
-       propagates, the process exits non-zero and the launcher tears the job down.
+    3. all ranks call ``ncclCommInitRank``.  A rank on which that call cannot even be entered (device binding, id
+       buffer, allocation: an error raised LOCALLY before the rendezvous) must not go on to a collective while its peers
+       are blocked inside ``ncclCommInitRank`` waiting for it: it exits non-zero at once and the launcher tears the job
+       down.  Only a failure reported by the rendezvous itself (every rank returns from it) is agreed on collectively,
+       and then every rank takes the host-staged exchange.
 
     Otherwise all ranks take the host-staged exchange -- decided collectively, reported in the bench line.
     """
@@ -178,6 +185,14 @@ def exchange_from_env(prefer="rccl", device_key=None):
         except Exception:  # noqa: BLE001
             ndev = 0
         device_key = (socket.gethostname(), local % ndev if ndev > 0 else local)
+        try:  # the physical device behind that index: launchers that isolate one GPU per rank give every rank index 0
+            import ctypes as C
+            from . import _lib
+            bus = C.create_string_buffer(64)
+            if _lib.load().figh_device_pci_bus_id(device_key[1], bus, 64) == 0 and bus.value:
+                device_key = (device_key[0], bus.value.decode())
+        except Exception:  # noqa: BLE001
+            pass
     states = [None] * world
     dist.all_gather_object(states, (bool(ok), why, tuple(device_key)))
     all_ok = all(s[0] for s in states)
@@ -202,6 +217,14 @@ def exchange_from_env(prefer="rccl", device_key=None):
         ex = RcclExchange(world, rank, payload[0])
     except Exception as e:  # noqa: BLE001
         err = str(e)
+        from . import _lib
+        if getattr(e, "code", None) != _lib.ERR_COMM:
+            # not an answer of the rendezvous (figh_comm_init reports those as FIGH_ERR_COMM): this rank never joined it,
+            # its peers are still inside ncclCommInitRank and no collective can be reached -- fail fast, no fallback
+            import sys
+            sys.stderr.write("rank %d: RCCL set-up failed before the rendezvous (%s); exiting\n" % (rank, err))
+            sys.stderr.flush()
+            os._exit(3)
     outcomes = [None] * world
     dist.all_gather_object(outcomes, (ex is not None, err))
     if all(o[0] for o in outcomes):

@@ -26,6 +26,7 @@ class Exchange:
 
     world_size = 1
     rank = 0
+    collective = False  # run() then folds the rank decision into the local merge tree; the exchanges below are bypassed
 
     def sum_columns(self, d_colsq, ncols):
         return d_colsq.to_host()
@@ -229,7 +230,7 @@ class IdentificationPipeline:
         for attempt in range(3):
             n = self._n_expected
             nc = n + (1 if with_tau else 0)
-            if ex.world_size == 1:
+            if not getattr(ex, "collective", True):
                 _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
                                    self.tol_qr, self._d_sel, self._d_rows)
             else:
@@ -261,6 +262,12 @@ class IdentificationPipeline:
             self._kept_cache = (kept_mask.copy(), list(idx_e), list(params_r))
         rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
         return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+
+    def device_columns(self, ref_cols):
+        """Column indices of the HBM-resident ``self.W`` that hold the reference's columns ``ref_cols`` (trees keep W
+        link-padded: 16 columns per link, reference column c at 16 (c // 14) + c % 14)."""
+        c = np.asarray(ref_cols, dtype=np.int64)
+        return (c // 14) * 16 + c % 14 if getattr(self, "_padded", False) else c
 
     def _place_W(self, rows, cols, handle, mode, flags, ft_mask):
         """Allocate W; with ``placement_trials`` > 1 keep the candidate allocation on which K1 runs fastest."""

@@ -57,6 +57,10 @@ int figh_device_set(int device);
  * process that exhausts it is frozen until the next 100 ms accounting period.  Call before figh_device_set / any
  * device call.  No reference analogue (the reference has no device). */
 int figh_host_wait_mode(int blocking);
+/* PCI bus id ("0000:c1:00.0") of HIP device `device`: the physical device a rank drives, whatever logical index the
+ * launcher's HIP_VISIBLE_DEVICES left it with (figaroh_plus_amd/dist.py: two ranks on one GPU cannot form an RCCL
+ * communicator).  Creates no context.  No reference analogue. */
+int figh_device_pci_bus_id(int device, char *out, int out_len);
 int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
 int figh_malloc(void **d_ptr, size_t bytes);
 int figh_free(void *d_ptr);

@@ -91,15 +91,20 @@ def _setup_worker(rank, world, port, out_dir, scenario):
         fd.rccl_preflight = lambda: (True, "")
     elif scenario == "shared_device":  # both ranks name the same GPU
         fd.rccl_preflight = lambda: (True, "")
-    elif scenario == "init_fails":     # preflight and id are fine, ncclCommInitRank errors out on one rank
+    elif scenario in ("init_fails", "init_local_failure"):
+        # preflight and id are fine; "init_fails": ncclCommInitRank itself reports an error on one rank (FIGH_ERR_COMM:
+        # every rank returns from the rendezvous); "init_local_failure": one rank cannot even enter it
         fd.rccl_preflight = lambda: (True, "")
+        from figaroh_plus_amd import _lib as flib
 
         class FakeRccl:
             closed = False
 
             def __init__(self, world_, rank_, ident):
+                if rank_ == 1 and scenario == "init_fails":
+                    raise flib.FighError(flib.ERR_COMM, "simulated: ncclCommInitRank failed on rank 1")
                 if rank_ == 1:
-                    raise RuntimeError("simulated: ncclCommInitRank failed on rank 1")
+                    raise RuntimeError("simulated: hipSetDevice failed on rank 1")
 
             def close(self):
                 calls["closed"] = calls.get("closed", 0) + 1
@@ -108,7 +113,7 @@ def _setup_worker(rank, world, port, out_dir, scenario):
 
     def unique_id():
         calls["unique_id"] += 1
-        if scenario == "init_fails":
+        if scenario in ("init_fails", "init_local_failure"):
             return b"0" * 128
         raise RuntimeError("simulated: ncclGetUniqueId failed")
 
@@ -158,3 +163,15 @@ def test_shard_range_partitions():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(P - 1))
             sizes = [hi - lo for lo, hi in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_rccl_local_setup_failure_fails_fast(tmp_path):
+    """a rank that fails BEFORE joining ncclCommInitRank (its peers are blocked inside the rendezvous) must
+    not wander off into a collective: it exits non-zero at once and the launcher tears the job down."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with pytest.raises(Exception) as e:
+        mp.spawn(_setup_worker, args=(2, port, str(tmp_path), "init_local_failure"), nprocs=2, join=True)
+    assert "exit code 3" in str(e.value) or "exitcode" in str(e.value).lower()
+    assert not os.path.exists(tmp_path / "rank1.json")

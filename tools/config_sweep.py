@@ -23,12 +23,12 @@ for cfg, mn in (("cfg1_tx40", "tx40"), ("cfg2_ur10", "ur10"), ("cfg3_tiago", "ti
     out = pipe.run()
     _lib.profile_enable(True); _lib.profile_reset()
     t0 = time.perf_counter(); out = pipe.run(); dt = time.perf_counter() - t0
-    prof = {k: round(_lib.profile_get(k)[1], 2) for k in ("regressor_chain", "regressor_tree", "colsq", "tsqr", "tsqr_reduce", "tsqr_small")}
+    prof = {k: round(_lib.profile_get(k)[1], 2) for k in ("regressor_chain", "regressor_tree", "colsq", "tsqr", "tsqr_tree", "tsqr_reduce", "tsqr_small")}
     _lib.profile_enable(False)
     same_e = out["idx_e"] == list(g["idx_e"]); same_b = out["idx_base"] == list(g["idx_base"])
     dep = [x for i, x in enumerate(out["absdiagR"]) if i not in set(out["idx_base"])]
     print("%-11s N=%d W %dx%d  step %.1f ms (%.2e samples/s)  idx_e ok %s  idx_base ok %s (%d)  max dep |Rii| %.1e  phi err %.1e  kernels(ms) %s" % (
-        cfg, N, pipe.W.rows, pipe.W.cols, dt * 1e3, N / dt, same_e, same_b, len(out["idx_base"]), max(dep) if dep else 0,
+        cfg, N, pipe.W.rows, pipe.W.ref_cols, dt * 1e3, N / dt, same_e, same_b, len(out["idx_base"]), max(dep) if dep else 0,
         (np.abs(out["phi_ls"] - g["phi_from_std"]).max() / np.abs(g["phi_from_std"]).max()) if same_b else float("nan"),
         prof), flush=True)
     del pipe

@@ -23,9 +23,9 @@ for N in (100_000, 400_000):
     print("N=%d: device base params %d, beyond the golden set: %s with |Rii| %s" % (
         N, len(out["idx_base"]), extra, ["%.2e" % d[i] for i in extra]), flush=True)
     if N == 400_000:
-        keep = [i for i in range(pipe.W.cols) if i not in set(out["idx_e"])]
+        keep = [i for i in range(pipe.W.ref_cols) if i not in set(out["idx_e"])]  # reference numbering ...
         t0 = time.perf_counter()
-        W = pipe.W.numpy()[:, keep]
+        W = pipe.W.numpy()[:, pipe.device_columns(keep)]                           # ... read from the link-padded W
         R = np.linalg.qr(W, mode="r")
         dl = np.abs(np.diag(R))
         lap = [i for i in range(len(keep)) if dl[i] > 1e-8]
