@@ -79,52 +79,73 @@ class _Threads:
         return False
 
 
-def cpu_baseline(flat, seed, n_cpu):
+def _cpu_inputs(robot, cfg, seed, n_cpu):
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
+    rng = np.random.default_rng(seed)
+    if cfg == "cfg2":
+        q, v, a = (rng.uniform(-6, 6, (n_cpu, 6)) for _ in range(3))
+    else:
+        q, v, a = sample_inputs(robot.model, n_cpu, rng, 1.5, 2, 5)
+    return q, v, a, rng.standard_normal(robot.model.nv * n_cpu)
+
+
+def cpu_baseline(robot, cfg, param, seed, n_cpu, n_config):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     cap = _baseline_threads()
     import cpu_baseline as cb  # oracle: measured here as the reported baseline, never shipped
 
-    rng = np.random.default_rng(seed)
-    q, v, a = (rng.uniform(-6, 6, (n_cpu, 6)) for _ in range(3))
-    tau = rng.standard_normal(6 * n_cpu)
+    flat = robot.model.to_flat()
+    q, v, a, tau = _cpu_inputs(robot, cfg, seed, n_cpu)
     with _Threads(cap):
         t0 = time.perf_counter()
-        _, stages = cb.faithful_pass(flat, q, v, a, tau)
+        _, stages = cb.faithful_pass(flat, q, v, a, tau, friction=bool(param["has_friction"]),
+                                     actuator_inertia=bool(param["has_actuator_inertia"]),
+                                     offset=bool(param["has_joint_offset"]))
         dt = time.perf_counter() - t0
         try:
             from threadpoolctl import threadpool_info
             blas = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
         except Exception:
             blas = os.cpu_count()
+    nv = robot.model.nv
+    note = ""
+    if cfg != "cfg2":
+        # where the faithful path cannot allocate the config's size (W and W_mod: 2 x 64.5 GB for TIAGo at
+        # 1e6 samples, plus Q of the two QRs), it is timed at the largest N that fits and the extrapolation is stated
+        note = ("; measured at N = %d because the reference structure needs 2 x %.1f GB for W / W_mod (+ explicit Q) at "
+                "the config's %d samples -- every stage is linear in N, so the rate carries over" % (
+                    n_cpu, 8.0 * nv * n_config * 14 * nv / 1e9, n_config))
     return {
         "value": n_cpu / dt, "unit": "samples/s", "cores": int(blas), "cpu_quota_cpus": cpu_quota(), "kind": "port",
-        "sample": "%d of the 1e6 UR10 samples, faithful reference structure (python per-sample loop around the C "
+        "sample": "%d of the %d %s samples, faithful reference structure (python per-sample loop around the C "
                   "regressor of oracle/, numpy scatter+permutation, np.diag(W.T@W), np.delete, 2x np.linalg.qr, "
-                  "pinv); host has %d logical cpus, BLAS threads %d; stage seconds %s" % (
-                      n_cpu, os.cpu_count(), blas, {k: round(x, 2) for k, x in stages.items()}),
+                  "pinv); host has %d logical cpus, BLAS threads %d; stage seconds %s%s" % (
+                      n_cpu, n_config, robot.model.name, os.cpu_count(), blas,
+                      {k: round(x, 2) for k, x in stages.items()}, note),
     }
 
 
-def cpu_baseline_fast(flat, seed, n_cpu):
+def cpu_baseline_fast(robot, cfg, param, seed, n_cpu, n_config):
     """The same pass with the host used well (OpenMP regressor in C, QR without Q): SURVEY 8(d) "fair-fast"."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cpu_baseline as cb
 
-    rng = np.random.default_rng(seed)
-    q, v, a = (rng.uniform(-6, 6, (n_cpu, 6)) for _ in range(3))
-    tau = rng.standard_normal(6 * n_cpu)
+    flat = robot.model.to_flat()
+    q, v, a, tau = _cpu_inputs(robot, cfg, seed, n_cpu)
+    flags = (1 if param["has_friction"] else 0) | (2 if param["has_actuator_inertia"] else 0) | (4 if param["has_joint_offset"] else 0)
+    nv = robot.model.nv
     cap = _baseline_threads()
     with _Threads(cap):
-        cb.fast_pass(flat, q[:2000], v[:2000], a[:2000], tau[:12000])  # thread pools up
+        cb.fast_pass(flat, q[:2000], v[:2000], a[:2000], tau[:nv * 2000], flags=flags)  # thread pools up
         t0 = time.perf_counter()
-        _, stages = cb.fast_pass(flat, q, v, a, tau)
+        _, stages = cb.fast_pass(flat, q, v, a, tau, flags=flags)
         dt = time.perf_counter() - t0
     return {"value": n_cpu / dt, "unit": "samples/s", "cores": cap or os.cpu_count(), "cpu_quota_cpus": cpu_quota(),
             "kind": "port",
-            "sample": "%d of the 1e6 UR10 samples, fair-fast structure (one OpenMP C call for the batch regressor, einsum "
+            "sample": "%d of the %d %s samples, fair-fast structure (one OpenMP C call for the batch regressor, einsum "
                       "column norms, np.linalg.qr(mode='r') of [W_e tau], regrouped QR of the triangle, triangular solves); "
                       "host has %d logical cpus, threads capped at the cgroup quota when there is one; stage seconds %s" % (
-                          n_cpu, os.cpu_count(), {k: round(x, 2) for k, x in stages.items()})}
+                          n_cpu, n_config, robot.model.name, os.cpu_count(), {k: round(x, 2) for k, x in stages.items()})}
 
 
 CONFIGS = {  # BASELINE.json configs[1..4]: (golden fixture, model, samples in the config, chunk for the streamed pass)
@@ -146,7 +167,8 @@ def main():
                     help="weak: --samples per GPU (default for cfg2); strong: the config's total sharded over the GPUs "
                          "(default for cfg3-5)")
     ap.add_argument("--samples", type=int, default=None, help="samples per GPU (weak) / in total (strong)")
-    ap.add_argument("--cpu-samples", type=int, default=300000)
+    ap.add_argument("--cpu-samples", type=int, default=None,
+                    help="samples of the CPU baseline legs (default: 300000 for cfg2, 20000 for cfg3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--placement-trials", type=int, default=4,
@@ -210,7 +232,12 @@ def main():
         q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
     pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
                                   chunk_samples=chunk, placement_trials=args.placement_trials)
+    _lib.synchronize()
+    t_h2d = time.perf_counter()
     pipe.set_samples(q, v, a)
+    _lib.synchronize()
+    t_h2d = time.perf_counter() - t_h2d
+    input_bytes = q.nbytes + v.nbytes + a.nbytes
     phi_ref = np.array([float(x) for x in meta["phi_ref_raw"]])
     pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config == "cfg2" else 0.0, seed=rank)
     del q, v, a
@@ -224,9 +251,12 @@ def main():
         out = pipe.run()
     _lib.profile_reset()
     barrier()
+    step_times = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe.run()
+        ts = time.perf_counter()
+        out = pipe.run()  # returns when its results are on the host: the per-step clock needs no extra synchronisation
+        step_times.append(time.perf_counter() - ts)
     barrier()
     dt = time.perf_counter() - t0
     _lib.profile_enable(False)
@@ -261,6 +291,16 @@ def main():
         if cnt:
             kern[name] = {"launches_per_step": cnt / 2.0, "avg_ms": ms / cnt, "timed_region": False}
     _lib.profile_enable(False)
+    transfers = {"h2d_inputs_ms": 1e3 * t_h2d, "h2d_inputs_GBps": input_bytes / t_h2d / 1e9, "timed_region": False}
+    if rank == 0 and pipe.W is not None and pipe.W.rows * pipe.W.ld * 8 <= 8e9:
+        # what the drop-in boundary pays when W itself is handed back to a NumPy caller (never part of `value`)
+        host_W = np.empty(pipe.W.rows * pipe.W.ld)
+        _lib.synchronize()
+        td = time.perf_counter()
+        _lib.check(lib.figh_memcpy_d2h(host_W.ctypes.data, pipe.W.buf.ptr, host_W.nbytes))
+        td = time.perf_counter() - td
+        transfers.update({"d2h_W_ms": 1e3 * td, "d2h_W_GBps": host_W.nbytes / td / 1e9, "W_bytes": host_W.nbytes})
+        del host_W
     m = robot.model
     rows_per_sample = m.nv if param["is_joint_torques"] else 6
     ncols = len(meta["names_std"])
@@ -293,19 +333,23 @@ def main():
     # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
     # tools/pmc_summary.py), i.e. from the builder's run, not from this one
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
+        pmc_file = next(n for n in ("r03_pmc_summary.json", "r02_pmc_summary.json")
+                        if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
         if args.config == "cfg2" and N == 1_000_000:
             for key, kname in (("regressor_chain", "regressor_chain_kernel<6, false, true>"),
                                ("tsqr", "tsqr2_kernel<4, 4, true>")):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
-                    roof[key]["traffic_source"] = ("profiles/r02_pmc_summary.json: a committed rocprofv3 --pmc run of this "
-                                                   "command, NOT measured in this run")
+                    roof[key]["traffic_source"] = ("profiles/%s: a committed rocprofv3 --pmc run of this command, NOT "
+                                                   "measured in this run" % pmc_file)
         if args.config == "cfg4" and N == 4_000_000:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_summary_cfg4.json")) as f:
+            pmc4 = next(n for n in ("r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
+                        if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", pmc4)) as f:
                 pmc = json.load(f)
-            src = "profiles/r02_pmc_summary_cfg4.json: a committed rocprofv3 --pmc run of this command, NOT measured in this run"
+            src = "profiles/%s: a committed rocprofv3 --pmc run of this command, NOT measured in this run" % pmc4
             for key, kname in (("regressor_tree", "regressor_tape_kernel<16, true, true, true, true>"),
                                ("tsqr", "tsqr_wy_kernel<4, 5, 4, 2, true>")):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
@@ -332,6 +376,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_median": 1e3 * float(np.median(step_times)),
+            "ms_per_step_min": 1e3 * float(np.min(step_times)),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -357,10 +403,18 @@ def main():
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
             "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},
+            "transfers": transfers,
         }
-        if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
-            line["cpu_baseline"] = cpu_baseline(robot.model.to_flat(), 7, args.cpu_samples)
-            line["cpu_baseline_fast"] = cpu_baseline_fast(robot.model.to_flat(), 7, args.cpu_samples)
+        if not args.no_cpu_baseline and world == 1 and args.config in ("cfg2", "cfg3"):
+            n_cpu = args.cpu_samples or (300000 if args.config == "cfg2" else 20000)
+            line["cpu_baseline"] = cpu_baseline(robot, args.config, param, 7, n_cpu, n_config)
+            line["cpu_baseline_fast"] = cpu_baseline_fast(robot, args.config, param, 7, n_cpu, n_config)
+            # BASELINE.md holds no published number for this metric; the ratio asked for is the one to the CPU path of
+            # the same pass measured in this run (fair-fast port; the faithful reference structure beside it)
+            line["vs_baseline"] = line["value"] / line["cpu_baseline_fast"]["value"]
+            line["vs_baseline_source"] = ("no published number exists (BASELINE.json published: {}); ratio of `value` to "
+                                          "cpu_baseline_fast of this run; vs the faithful reference structure: %.0fx" % (
+                                              line["value"] / line["cpu_baseline"]["value"]))
         print(json.dumps(line))
     if world > 1:
         barrier()

@@ -16,9 +16,10 @@ import numpy as np
 import oracle_c
 
 
-def faithful_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8):
-    """One pass of the hot path on the CPU for a joint-torque model without extra columns
-    (BASELINE config 2).  Returns (result dict, seconds per stage)."""
+def faithful_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8, friction=False, actuator_inertia=False, offset=False):
+    """One pass of the hot path on the CPU for a joint-torque model (BASELINE configs 2 and 3; the friction /
+    actuator-inertia / offset columns of regressor.py:55-70 when the flags are set).  Returns (result dict, seconds per
+    stage)."""
     om = oracle_c.OracleModel(flat)
     N, nv = len(q), om.nv
     t = {}
@@ -30,10 +31,20 @@ def faithful_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8):
         W_temp = om.joint_torque_regressor(q[i, :], v[i, :], a[i, :], out=Y)
         for j in range(W_temp.shape[0]):
             W[j * N + i, 0:10 * nv] = W_temp[j, :]
-            W[j * N + i, 10 * nv + 2 * j] = 0
-            W[j * N + i, 10 * nv + 2 * j + 1] = 0
-            W[j * N + i, 10 * nv + 2 * nv + j] = 0
-            W[j * N + i, 10 * nv + 2 * nv + nv + j] = 0
+            if friction:
+                W[j * N + i, 10 * nv + 2 * j] = v[i, j]
+                W[j * N + i, 10 * nv + 2 * j + 1] = np.sign(v[i, j])
+            else:
+                W[j * N + i, 10 * nv + 2 * j] = 0
+                W[j * N + i, 10 * nv + 2 * j + 1] = 0
+            if actuator_inertia:
+                W[j * N + i, 10 * nv + 2 * nv + j] = a[i, j]
+            else:
+                W[j * N + i, 10 * nv + 2 * nv + j] = 0
+            if offset:
+                W[j * N + i, 10 * nv + 2 * nv + nv + j] = 1
+            else:
+                W[j * N + i, 10 * nv + 2 * nv + nv + j] = 0
     src = [4, 5, 7, 6, 8, 9, 1, 2, 3, 0]
     for k in range(nv):
         for dst in range(10):
@@ -68,7 +79,7 @@ def faithful_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8):
     return out, t
 
 
-def fast_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8):
+def fast_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8, flags=0):
     """"Fair-fast" flavour: the same results with the CPU used well -- one native call for the
     whole batch (oracle/figh_oracle.c, OpenMP over the samples, W written once in its final layout), column norms
     without the Gram product, ``np.linalg.qr(mode='r')`` of [W_e tau] (no Q), the regrouped factorisation on the
@@ -76,7 +87,7 @@ def fast_pass(flat, q, v, a, tau=None, tol_e=1e-6, tol_qr=1e-8):
     om = oracle_c.OracleModel(flat)
     t = {}
     t0 = time.perf_counter()
-    W = om.build_regressor_basic(q, v, a, 0, 0)
+    W = om.build_regressor_basic(q, v, a, 0, flags)
     t["regressor"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     col_norm = np.einsum("ij,ij->j", W, W)
