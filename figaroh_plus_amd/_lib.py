@@ -19,7 +19,7 @@ FIGH_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5
 
 MODE_JOINT_TORQUE, MODE_EXT_WRENCH = 0, 1
-FLAG_FRICTION, FLAG_ACT_INERTIA, FLAG_OFFSET, FLAG_TX40, FLAG_GENERIC = 1, 2, 4, 8, 256
+FLAG_FRICTION, FLAG_ACT_INERTIA, FLAG_OFFSET, FLAG_TX40, FLAG_GENERIC, FLAG_BLOCKED_INPUTS = 1, 2, 4, 8, 256, 512
 
 _c_double_p = C.POINTER(C.c_double)
 _c_int32_p = C.POINTER(C.c_int32)
@@ -51,6 +51,7 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "figh_regressor_build_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "figh_repack_samples": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "figh_coupling_tx40": (C.c_int, [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "figh_colsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p]),
     "figh_gather_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -367,3 +368,10 @@ def tsqr_selected(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, nblocks, n
 
 def tsqr_merge_base(d_Rs, count, nc, n_free, tol_qr, d_Rk):
     check(load().figh_tsqr_merge_base(d_Rs.ptr, count, nc, n_free, tol_qr, d_Rk.ptr))
+
+
+def repack_samples(d_src, N, width):
+    """Tile-blocked copy of a sample-major N x width device array (figh_repack_samples): a new DeviceArray."""
+    d_dst = DeviceArray((((N + 63) // 64) * 64 * width,), np.float64)
+    check(load().figh_repack_samples(d_src.ptr, N, width, d_dst.ptr))
+    return d_dst

@@ -434,6 +434,39 @@ extern "C" int figh_coupling_tx40(int64_t N, int nv, const double *d_v, const do
     return FIGH_OK;
 }
 
+// 64 x width block of a sample-major array -> [value][lane]: read as one contiguous run, transposed through LDS
+__global__ __launch_bounds__(256) void repack_samples_kernel(const double *__restrict__ src, const long N, const int width,
+                                                             double *__restrict__ dst) {
+    extern __shared__ double blk[];  // 64 x (width + 1)
+    const long t = blockIdx.x;
+    const long i0 = t * 64;
+    const int nvalid = (int)((N - i0) < 64 ? (N - i0) : 64);
+    const int ld = width | 1;  // odd stride: the transposed reads spread over the banks
+    for (int e = threadIdx.x; e < 64 * width; e += 256) {
+        const int l = e / width, k = e - l * width;
+        blk[l * ld + k] = src[(i0 + (l < nvalid ? l : nvalid - 1)) * width + k];
+    }
+    __syncthreads();
+    double *out = dst + t * 64 * width;
+    for (int e = threadIdx.x; e < 64 * width; e += 256) {
+        const int k = e >> 6, l = e & 63;
+        out[e] = blk[l * ld + k];
+    }
+}
+
+extern "C" int figh_repack_samples(const double *d_src, int64_t N, int width, double *d_dst) {
+    FIGH_REQUIRE(d_src && d_dst, "NULL device pointer");
+    FIGH_REQUIRE(N >= 0 && width >= 1 && width <= 256, "figh_repack_samples: 1 .. 256 values per sample");
+    if (int rc = ensure_device()) return rc;
+    if (N == 0) return FIGH_OK;
+    ProfileScope scope("repack_samples");
+    const long ntiles = (N + 63) / 64;
+    hipLaunchKernelGGL(repack_samples_kernel, dim3((unsigned)ntiles), dim3(256), sizeof(double) * 64 * (width | 1), stream(),
+                       d_src, (long)N, width, d_dst);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
 extern "C" int figh_regressor_build(figh_model_t model, int mode, int flags, int ft_mask, int64_t N,
                                     const double *d_q, const double *d_v, const double *d_a, double *d_W, int64_t ldw,
                                     double *d_colsq) {
@@ -458,6 +491,8 @@ extern "C" int figh_regressor_build(figh_model_t model, int mode, int flags, int
     const bool tx40 = flags & FIGH_FLAG_TX40;
     int rc;
     if (model->is_chain && mode == FIGH_MODE_JOINT_TORQUE && !(flags & FIGH_FLAG_GENERIC)) {
+        FIGH_REQUIRE(!(flags & FIGH_FLAG_BLOCKED_INPUTS), "tile-blocked inputs are for the generic-tree kernel (the chain "
+                                                          "kernel reads 48-byte runs per lane from the original arrays)");
         const int f = flags & 7;
         switch (h.nlinks) {
 #define FIGH_CHAIN_CASE(NJ)                                                                             \
@@ -512,5 +547,6 @@ extern "C" int figh_regressor_build_padded(figh_model_t model, int mode, int fla
         return FIGH_OK;
     }
     int done = 0;
-    return launch_regressor_tree(model, mode, flags & 7, ft_mask, N, d_q, d_v, d_a, d_W, ldw, ncols, 16, d_colsq, &done);
+    return launch_regressor_tree(model, mode, flags & (7 | FIGH_FLAG_BLOCKED_INPUTS), ft_mask, N, d_q, d_v, d_a, d_W, ldw,
+                                 ncols, 16, d_colsq, &done);
 }

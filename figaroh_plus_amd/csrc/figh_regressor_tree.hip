@@ -172,6 +172,8 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
     const unsigned ldw8 = 8u * (unsigned)ldw;
     const int nq = M->nq, nv = M->nv;
     const bool fric = flags & FIGH_FLAG_FRICTION, actin = flags & FIGH_FLAG_ACT_INERTIA, offs = flags & FIGH_FLAG_OFFSET;
+    const bool blocked = flags & FIGH_FLAG_BLOCKED_INPUTS;
+    const int is = blocked ? 64 : 1;
     if constexpr (COLSQ) {
         for (int e = lane; e < ncols_int; e += 64) colacc[e] = 0.0;
     }
@@ -185,14 +187,19 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
         const long i0 = t * 64;
         const int nvalid = (int)((N - i0) < 64 ? (N - i0) : 64);
         const long i = i0 + (lane < nvalid ? lane : nvalid - 1);
+        // value k of this lane's sample is qi[k * is]: is = 1 for the reference's sample-major arrays, 64 for the
+        // tile-blocked copies of figh_repack_samples (FIGH_FLAG_BLOCKED_INPUTS: the wave's 64 values of one k are one line)
 #ifdef FIGH_ABLATION
         // FIGH_TREE_HOTIN: every tile reads the inputs of the first 64 samples (wrong numbers, same instruction stream):
         // what the kernel would cost if q, v, a came from cache (tools/tree_hotin.sh)
         const long iin = g_tree_hotin ? (lane < nvalid ? lane : nvalid - 1) : i;
-        const double *qi = q + iin * nq, *vi = v + iin * nv, *ai = a + iin * nv;
+        const long tin = g_tree_hotin ? 0 : t;
 #else
-        const double *qi = q + i * nq, *vi = v + i * nv, *ai = a + i * nv;
+        const long iin = i, tin = t;
 #endif
+        const double *qi = blocked ? q + tin * 64 * nq + lane : q + iin * nq;
+        const double *vi = blocked ? v + tin * 64 * nv + lane : v + iin * nv;
+        const double *ai = blocked ? a + tin * 64 * nv + lane : a + iin * nv;
         // state of the current link
         double V[6] = {0, 0, 0, 0, 0, 0}, A[6] = {-g0, -g1, -g2, 0, 0, 0};
         double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};  // EXTFF: link -> root-joint frame
@@ -249,16 +256,16 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                         aj[d] = ax[d] * jqdd;
                     }
                 } else {  // free-flyer: q = [p, qx qy qz qw], v in the joint's local frame (read here: once per walk)
-                    const double x = qi[iq + 3], y = qi[iq + 4], z = qi[iq + 5], ww = qi[iq + 6];
+                    const double x = qi[(iq + 3) * is], y = qi[(iq + 4) * is], z = qi[(iq + 5) * is], ww = qi[(iq + 6) * is];
                     Rj[0] = 1 - 2 * (y * y + z * z); Rj[1] = 2 * (x * y - z * ww); Rj[2] = 2 * (x * z + y * ww);
                     Rj[3] = 2 * (x * y + z * ww); Rj[4] = 1 - 2 * (x * x + z * z); Rj[5] = 2 * (y * z - x * ww);
                     Rj[6] = 2 * (x * z - y * ww); Rj[7] = 2 * (y * z + x * ww); Rj[8] = 1 - 2 * (x * x + y * y);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) pj[d] = qi[iq + d];
+                    for (int d = 0; d < 3; ++d) pj[d] = qi[(iq + d) * is];
 #pragma unroll
                     for (int d = 0; d < 6; ++d) {
-                        vj[d] = vi[iv + d];
-                        aj[d] = ai[iv + d];
+                        vj[d] = vi[(iv + d) * is];
+                        aj[d] = ai[(iv + d) * is];
                     }
                 }
                 double Rk[9], pk[3];  // liMi = placement * M_joint(q)
@@ -338,9 +345,9 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                 if (oc & EMIT_EXTRA) {  // regressor.py:55-70 (own row) / :142-169 (all six rows): Ia fv fs off of link b
                     // joint-torque mode writes them on the link's own row, right after its STEP: dof b - 1 is that joint
                     const bool own = oc & EMIT_OWN;
-                    if (actin) ex[0] = own ? last_qdd : ai[b - 1];
+                    if (actin) ex[0] = own ? last_qdd : ai[(b - 1) * is];
                     if (fric) {
-                        const double vv = own ? last_qd : vi[b - 1];
+                        const double vv = own ? last_qd : vi[(b - 1) * is];
                         ex[1] = vv;
                         ex[2] = sgn(vv);
                     }
@@ -409,10 +416,10 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                 for (int s = 0; s < kFetch; ++s)
                     if (js[s] > 0) {
                         const int iq = M->idx_q[js[s]], iv = M->idx_v[js[s]];
-                        sq0[s] = qi[iq];
-                        sq1[s] = M->jtype[js[s]] == FIGH_JT_CONTINUOUS ? qi[iq + 1] : 0.0;
-                        sqd[s] = vi[iv];
-                        sqdd[s] = ai[iv];
+                        sq0[s] = qi[iq * is];
+                        sq1[s] = M->jtype[js[s]] == FIGH_JT_CONTINUOUS ? qi[(iq + 1) * is] : 0.0;
+                        sqd[s] = vi[iv * is];
+                        sqdd[s] = ai[iv * is];
                     }
             } else if (op == OP_RESET) {
 #pragma unroll
@@ -425,11 +432,11 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
             } else {  // OP_TX40 (regressor.py:198-227, fused): columns 14 nl .. + 2 on the six joint rows
                 if constexpr (STORE) {
                     if (lane < nvalid) {
-                        const double sc = sgn(vi[4] + vi[5]);
+                        const double sc = sgn(vi[4 * is] + vi[5 * is]);
                         for (int r = 0; r < 6; ++r) {
                             double *row = W + ((long)r * N + i) * ldw + oa;
-                            row[0] = r == 4 ? ai[5] : (r == 5 ? ai[4] : 0.0);
-                            row[1] = r == 4 ? vi[5] : (r == 5 ? vi[4] : 0.0);
+                            row[0] = r == 4 ? ai[5 * is] : (r == 5 ? ai[4 * is] : 0.0);
+                            row[1] = r == 4 ? vi[5 * is] : (r == 5 ? vi[4 * is] : 0.0);
                             row[2] = (r == 4 || r == 5) ? sc : 0.0;
                         }
                     }

@@ -93,6 +93,8 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     if (chunk_samples == 0) chunk_samples = default_chunk(rps, ncols);
     const int64_t cs = chunk_samples < N ? chunk_samples : N;
     const int64_t nchunks = (N + cs - 1) / cs;
+    FIGH_REQUIRE(!(flags & FIGH_FLAG_BLOCKED_INPUTS) || nchunks == 1 || cs % 64 == 0,
+                 "tile-blocked inputs: chunk_samples must be a multiple of 64");
     // the chunk's W is a private workspace: tree models get the link-padded layout (16 columns per link, every row
     // segment one 128-byte line) and the caller's column list is translated to it
     const bool padded = !(model->is_chain && mode == FIGH_MODE_JOINT_TORQUE) && !(flags & FIGH_FLAG_TX40);

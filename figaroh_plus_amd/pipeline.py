@@ -92,8 +92,33 @@ class IdentificationPipeline:
                                  % (rps, len(q), rps * len(q), tau.shape[0]))
         N, d_q, d_v, d_a = _samples_to_device(self.robot.model, q, v, a)  # raises ValueError on a shape mismatch
         d_tau = None if tau is None else _lib.DeviceArray.from_host(tau)
+        # Tree models: the generic regressor kernel takes one sample per lane, and in the reference's sample-major arrays a
+        # lane's values lie nq * 8 bytes from its neighbour's.  The three arrays are re-laid once per tile of 64 samples,
+        # value-major (figh_repack_samples); K1' then reads one 512-byte line per value.  Chains keep the original arrays
+        # (their kernel reads 48-byte runs per lane).
+        self._in_flags, self.repack_ms = 0, 0.0
+        m = self.robot.model
+        if N > 0 and not (self.robot.device_model().is_chain() and mode == _lib.MODE_JOINT_TORQUE) and not self.coupling:
+            import time
+            _lib.synchronize()
+            t0 = time.perf_counter()
+            blocked = [_lib.repack_samples(d, N, w) for d, w in ((d_q, m.nq), (d_v, m.nv), (d_a, m.nv))]
+            _lib.synchronize()
+            self.repack_ms = 1e3 * (time.perf_counter() - t0)
+            for d in (d_q, d_v, d_a):
+                d.free()
+            d_q, d_v, d_a = blocked
+            self._in_flags = _lib.FLAG_BLOCKED_INPUTS
+            if self.chunk_samples:
+                self.chunk_samples = max(64, (int(self.chunk_samples) // 64) * 64)  # chunks start on tile boundaries
         self.N, self.d_q, self.d_v, self.d_a, self.d_tau = N, d_q, d_v, d_a, d_tau
         self.W = None
+
+    def _flags(self):
+        """(mode, flags, ft_mask) of this pipeline's regressor calls, including the layout of its input arrays."""
+        from .tools.regressor import regressor_flags
+        mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+        return mode, flags | getattr(self, "_in_flags", 0), ft_mask
 
     def _chunks(self):
         c = self.chunk_samples
@@ -103,8 +128,7 @@ class IdentificationPipeline:
         return bool(self.chunk_samples) and self.N > self.chunk_samples
 
     def _build_chunk(self, lo, hi, W, d_colsq):
-        from .tools.regressor import regressor_flags
-        mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+        mode, flags, ft_mask = self._flags()
         m = self.robot.model
         _lib.regressor_build(self.robot.device_model(), mode, flags, ft_mask, hi - lo, _View(self.d_q, lo * m.nq * 8),
                              _View(self.d_v, lo * m.nv * 8), _View(self.d_a, lo * m.nv * 8), W.buf, W.ld, d_colsq)
@@ -119,8 +143,7 @@ class IdentificationPipeline:
     def set_tau_from_parameters(self, phi, noise_std=0.0, seed=0):
         """Synthetic measurement tau = W phi + noise, built on the device (bench / tests)."""
         if self._chunked():
-            from .tools.regressor import regressor_flags
-            mode, flags, _ = regressor_flags(self.param, self.coupling)
+            mode, flags, _ = self._flags()
             rps, ncols = self.robot.device_model().shape(mode, flags)
             d_phi = _lib.DeviceArray.from_host(np.ascontiguousarray(phi, dtype=np.float64))
             self.d_tau = _lib.DeviceArray((rps * self.N,), np.float64)
@@ -135,7 +158,8 @@ class IdentificationPipeline:
                 tau += np.random.default_rng(seed).standard_normal(tau.shape[0]) * noise_std
                 self.d_tau = _lib.DeviceArray.from_host(tau)
             return self.d_tau
-        W, _ = build_regressor_device(self.robot, self.d_q, self.d_v, self.d_a, self.N, self.param, self.coupling)
+        W, _ = build_regressor_device(self.robot, self.d_q, self.d_v, self.d_a, self.N, self.param, self.coupling,
+                                      extra_flags=self._in_flags)
         d_phi = _lib.DeviceArray.from_host(np.ascontiguousarray(phi, dtype=np.float64))
         d_tau = _lib.DeviceArray((W.rows,), np.float64)
         _lib.matvec(W.buf, W.rows, W.ld, None, W.cols, d_phi, d_tau)
@@ -151,9 +175,8 @@ class IdentificationPipeline:
     def _run_chunked(self, strings):
         """Memory-bounded pass through the streamed C-ABI entry points (W exists one chunk at a time, in a library
         workspace): figh_regressor_colsq for the elimination, figh_regressor_tsqr for the triangle."""
-        from .tools.regressor import regressor_flags
         ex, lib = self.exchange, _lib.load()
-        mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+        mode, flags, ft_mask = self._flags()
         dm = self.robot.device_model()
         rps, ncols = dm.shape(mode, flags)
         if getattr(self, "_dc_colsq", None) is None or self._dc_colsq.size != ncols:
@@ -190,8 +213,7 @@ class IdentificationPipeline:
             return self._run_chunked(strings)
         ex = self.exchange
         # K1 (+ fused column norms)
-        from .tools.regressor import regressor_flags
-        mode, flags, ft_mask = regressor_flags(self.param, self.coupling)
+        mode, flags, ft_mask = self._flags()
         handle = self.robot.device_model()
         if self.W is None:  # HBM buffers are allocated once and reused by every step
             self._kept_cache = None

@@ -55,9 +55,11 @@ def _samples_to_device(model, q, v, a):
         _lib.DeviceArray.from_host(a.reshape(-1))
 
 
-def build_regressor_device(robot, d_q, d_v, d_a, N, param, coupling=False, colsq=False):
-    """Device-to-device core of :func:`build_regressor_basic`: returns (GpuMatrix W, DeviceArray colsq|None)."""
+def build_regressor_device(robot, d_q, d_v, d_a, N, param, coupling=False, colsq=False, extra_flags=0):
+    """Device-to-device core of :func:`build_regressor_basic`: returns (GpuMatrix W, DeviceArray colsq|None).
+    ``extra_flags``: e.g. ``_lib.FLAG_BLOCKED_INPUTS`` when d_q / d_v / d_a are the tile-blocked copies."""
     mode, flags, ft_mask = regressor_flags(param, coupling)
+    flags |= extra_flags
     handle = robot.device_model()
     rows_per_sample, ncols = handle.shape(mode, flags)
     W = GpuMatrix.empty(rows_per_sample * N, ncols)

@@ -42,7 +42,12 @@ enum { FIGH_MODE_JOINT_TORQUE = 0, FIGH_MODE_EXT_WRENCH = 1 };
 /* flags: param["has_friction"], ["has_actuator_inertia"], ["has_joint_offset"] (regressor.py:55-70, :144-169);
  * FIGH_FLAG_TX40 appends the 3 coupling columns of add_coupling_TX40 (regressor.py:198-227);
  * FIGH_FLAG_GENERIC forces the generic-tree kernel even when the serial-chain kernel applies (tests). */
-enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, FIGH_FLAG_TX40 = 8, FIGH_FLAG_GENERIC = 256 };
+enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, FIGH_FLAG_TX40 = 8, FIGH_FLAG_GENERIC = 256,
+       /* d_q / d_v / d_a are TILE-BLOCKED copies made by figh_repack_samples ([tile of 64 samples][value][lane]) instead of
+        * the reference's sample-major arrays: the generic-tree kernel then reads one 512-byte line per value and wave
+        * (sample-major, a lane's values lie nq * 8 bytes from its neighbour's and every 8-byte load pulls a line of its
+        * own: 7.4x the algorithmic input bytes on TALOS).  Tree models only. */
+       FIGH_FLAG_BLOCKED_INPUTS = 512 };
 
 typedef struct figh_model_s *figh_model_t;
 
@@ -110,6 +115,13 @@ int figh_regressor_build(figh_model_t model, int mode, int flags, int ft_mask, i
  * (14 (njoints-1) entries).  figh_tsqr / figh_matvec / figh_gather_cols take such a W through their column lists. */
 int figh_regressor_build_padded(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
                                 const double *d_v, const double *d_a, double *d_W, int64_t ldw, double *d_colsq);
+
+/* figh_repack_samples: d_dst[(t * width + k) * 64 + l] = d_src[min(64 t + l, N - 1) * width + k] -- a sample-major N x width
+ * array (q, v or a exactly as the reference holds them) re-laid per tile of 64 samples, value-major inside the tile, the
+ * last tile padded with its last sample.  d_dst: ceil(N / 64) * 64 * width doubles.  The copies are what
+ * FIGH_FLAG_BLOCKED_INPUTS announces; a chunk of samples [lo, lo + n) with lo % 64 == 0 starts at d_dst + lo * width, like
+ * in the original. */
+int figh_repack_samples(const double *d_src, int64_t N, int width, double *d_dst);
 
 /* add_coupling_TX40 as a separate call (regressor.py:198-227), for callers that append the three columns
  * [Iam6 fvm6 fsm6] to an existing W: d_out is (6N x 3) row-major, rows in the same joint-major order; only the

@@ -1284,3 +1284,52 @@ def test_pipeline_through_rccl_exchange_of_one_rank(lib, golden_ur10):
             assert abs(out["residual_norm"] - out0["residual_norm"]) <= 1e-9 * out0["residual_norm"]
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("N,width", [(1, 5), (63, 39), (64, 38), (65, 7), (400, 46), (1000, 1)])
+def test_repack_samples_layout(lib, N, width):
+    """figh_repack_samples: [tile of 64 samples][value][lane], the last tile padded with its last sample."""
+    rng = np.random.default_rng(N + width)
+    x = rng.standard_normal((N, width))
+    d = lib.repack_samples(lib.DeviceArray.from_host(x.reshape(-1)), N, width)
+    got = d.to_host().reshape(-1, width, 64)
+    nt = (N + 63) // 64
+    pad = np.concatenate([x, np.repeat(x[-1:], nt * 64 - N, axis=0)]).reshape(nt, 64, width).transpose(0, 2, 1)
+    assert np.array_equal(got, pad)
+
+
+def test_tree_regressor_blocked_inputs_identical(lib, golden):
+    """FIGH_FLAG_BLOCKED_INPUTS: the generic-tree kernel on the tile-blocked copies of q, v, a writes the same W and the
+    same column norms, bit for bit, as on the reference's sample-major arrays (all models through the tape kernel; chains
+    with the generic-kernel flag; ragged last tile)."""
+    from figaroh_plus_amd.tools.regressor import regressor_flags
+    g = golden
+    robot = g.robot()
+    m = robot.model
+    q, v, a = g["q_big"], g["v_big"], g["a_big"]
+    N = len(q)
+    mode, flags, ft = regressor_flags(dict(g.param, force_generic_kernel=True), g.coupling)
+    dm = robot.device_model()
+    rps, ncols = dm.shape(mode, flags)
+    dq, dv, da = (lib.DeviceArray.from_host(np.ascontiguousarray(x).reshape(-1)) for x in (q, v, a))
+    bq, bv, ba = lib.repack_samples(dq, N, m.nq), lib.repack_samples(dv, N, m.nv), lib.repack_samples(da, N, m.nv)
+    outs = []
+    for (xq, xv, xa), fl in (((dq, dv, da), flags), ((bq, bv, ba), flags | lib.FLAG_BLOCKED_INPUTS)):
+        W = lib.DeviceArray((rps * N * ncols,))
+        cs = lib.DeviceArray((ncols,))
+        lib.regressor_build(dm, mode, fl, ft, N, xq, xv, xa, W, ncols, cs)
+        outs.append((W.to_host(), cs.to_host()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    if not g.coupling and not (dm.is_chain() and mode == lib.MODE_JOINT_TORQUE):
+        ld = 16 * (m.njoints - 1)
+        outs = []
+        for (xq, xv, xa), fl in (((dq, dv, da), flags & 7), ((bq, bv, ba), (flags & 7) | lib.FLAG_BLOCKED_INPUTS)):
+            W = lib.DeviceArray((rps * N * ld,))
+            cs = lib.DeviceArray((ncols,))
+            lib.regressor_build_padded(dm, mode, fl, ft, N, xq, xv, xa, W, ld, cs)
+            outs.append((W.to_host(), cs.to_host()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    else:
+        with pytest.raises(lib.FighError):  # the chain kernel keeps the original arrays
+            lib.regressor_build(dm, mode, (flags & ~lib.FLAG_GENERIC) | lib.FLAG_BLOCKED_INPUTS, ft, N, bq, bv, ba,
+                                lib.DeviceArray((rps * N * ncols,)), ncols, None)
