@@ -94,6 +94,8 @@ void forget_tapes(const figh_model_s *m);
 long tsqr_wide_workgroups(int nc, int cus);
 int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
                      const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out);
+// figh_tsqr_wide_pair.hip: one pair-merge level, `count` stacked triangles -> (count + 1) / 2
+int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_out);
 
 // figh_tsqr_tree.hip: every merge level of the register-tile TSQR (nc <= 80) in one launch: `count` stacked triangles ->
 // the plain triangle d_out; d_rows_out != nullptr appends the rank decision (columns k < n_free, threshold tol) and the

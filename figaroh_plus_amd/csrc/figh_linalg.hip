@@ -748,11 +748,13 @@ static int tsqr_reduce(const double *Rs, long count, int nc, double *d_R_out) {
                 hipLaunchKernelGGL((tsqr_coop_kernel<4, 4>), dim3((unsigned)nb), dim3(256), 0, stream(), cur, rows, nc, dst);
             FIGH_HIP(hipGetLastError());
         } else {
-            const long want = (cnt + 3) / 4;
-            dst = want == 1 ? d_R_out : static_cast<double *>(workspace(tri * want, slot));
+            // pairs: a workgroup starts FROM its first triangle and absorbs the second (66 panel phases for TALOS'
+            // 331 columns); a level costs (fan-in - 1) absorptions and there are log_fan(count) of them, so 2 is the
+            // fan-in (round 2 walked four triangles into an empty one per level: 12.7 ms for 512 triangles)
+            nb = (cnt + 1) / 2;
+            dst = nb == 1 ? d_R_out : static_cast<double *>(workspace(tri * nb, slot));
             if (!dst) return FIGH_ERR_ALLOC;
-            if (int rc = tsqr_level(cur, cnt * nc, nc, nullptr, nc, nullptr, nullptr, 1, nc, want, dst, &nb, nullptr))
-                return rc;
+            if (int rc = launch_tsqr_wide_pairs(cur, cnt, nc, dst)) return rc;
         }
         cur = dst;
         cnt = nb;

@@ -1046,10 +1046,13 @@ def test_select_columns_on_device(lib, stride):
 
 
 @pytest.mark.parametrize("nc,count", [(1, 5), (17, 40), (50, 2), (50, 16), (50, 300), (50, 2039), (64, 700), (65, 9), (80, 130),
-                                      (49, 4500)])
+                                      (49, 4500), (81, 2), (120, 7), (191, 33), (241, 5), (331, 16), (336, 3), (400, 2),
+                                      (511, 3)])
 def test_merge_tree_against_lapack(lib, nc, count):
     """figh_tsqr_merge: every level in one launch (figh_tsqr_tree.hip) -- one, two and three levels, both tile
-    geometries, and the stack that is too tall for one resident grid (4500 triangles: per-level launches)."""
+    geometries, and the stack that is too tall for one resident grid (4500 triangles: per-level launches); nc > 80: the
+    pair-merge levels of the blocked kernel (a workgroup starts from one triangle and absorbs the next; odd counts pass
+    the last triangle through), every geometry."""
     rng = np.random.default_rng(nc * 1000 + count)
     stack = np.triu(rng.standard_normal((count, nc, nc)))
     stack[:, :, nc // 2] *= 1e-3

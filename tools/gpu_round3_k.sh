@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/r03/r03_gputest_summary.txt
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03/r03_bench.json 2> gpurun_out/r03/bench.err; tail -c 600 gpurun_out/r03/r03_bench.json | head -c 300; echo
+timeout 1200 python tools/shard_sweep.py cfg2 cfg3 cfg4 cfg5 > gpurun_out/r03/r03_shard_sweep.json 2> gpurun_out/r03/shard.err; tail -5 gpurun_out/r03/shard.err
