@@ -759,7 +759,7 @@ struct WyConfig {
 
 // Geometry by column count (one wave per SIMD throughout, see tsqr_wy_kernel): as few waves per workgroup -- as many
 // independent panel chains per CU -- as the register file allows for the workgroup's tile.
-WyConfig wy_config(const int nc) {
+[[maybe_unused]] WyConfig wy_config(const int nc) {
     const int nch = (nc + 15) >> 4;
 #ifdef FIGH_ABLATION
     if (const char *e = getenv("FIGH_WY_CFG")) {  // "nw,cpw,nrc,wpe" (ablation build only)

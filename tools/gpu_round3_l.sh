@@ -1,8 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "merge or full_size_talos or full_size_tiago or pipeline_matches" 2>&1 | grep -E "passed|failed|error" | tail -3
-python tools/wide_merge_bench.py 331 2>&1 | tee gpurun_out/r03/wide_merge_bench.txt
-for c in cfg4 cfg3; do
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "merge or full_size_talos or full_size_tiago or pipeline_matches or human" 2>&1 | grep -E "passed|failed|error" | tail -3
+python tools/wide_merge_bench.py 191 241 331 400 2>&1 | grep -v "count    8\|count   64" | tee gpurun_out/r03/wide_merge_bench.txt
+for c in cfg4; do
 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
