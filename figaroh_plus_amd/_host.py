@@ -42,3 +42,45 @@ def host_tail(fn):
             return fn(*args, **kwargs)
 
     return wrapper
+
+
+def cpu_budget():
+    """CPUs this process may actually burn: the scheduler affinity capped by the cgroup quota (cpu.max) when there is one
+    -- the GPU boxes show 256 logical CPUs under a quota of 16, and a process that exceeds it is frozen (see above)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def singular_values_batch(R):
+    """Singular values of a stack of n x n matrices (B x n x n) -> B x n, descending.  The B factorisations are
+    independent LAPACK calls that release the interpreter lock: with BLAS on one thread each they run on a small pool of
+    threads, half the CPU budget at most (a 180 x 180 SVD is about 1 ms, 64 of them would otherwise be the whole cost of
+    a batched objective whose device part takes 7.5 ms)."""
+    import numpy as np
+    R = np.asarray(R)
+    B = R.shape[0]
+    workers = min(B, max(1, cpu_budget() // 2), 8)
+    if workers <= 1 or B < 4:
+        return np.linalg.svd(R, compute_uv=False)
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty(R.shape[:2])
+
+    def work(lo, hi):
+        with single_threaded_blas():
+            out[lo:hi] = np.linalg.svd(R[lo:hi], compute_uv=False)
+
+    bounds = np.linspace(0, B, workers + 1).astype(int)
+    with ThreadPoolExecutor(workers) as pool:
+        list(pool.map(lambda k: work(bounds[k], bounds[k + 1]), range(workers)))
+    return out

@@ -73,6 +73,8 @@ SIGNATURES = {
     "figh_regressor_tsqr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int, C.c_int64,
                                       C.c_void_p]),
+    "figh_regressor_tsqr_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "figh_regressor_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _c_double_p, _c_double_p,
                                       _c_double_p]),
@@ -318,6 +320,13 @@ def regressor_tsqr(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_ta
     check(load().figh_regressor_tsqr(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr,
                                      d_idx.ptr if d_idx is not None else None, n,
                                      d_tau.ptr if d_tau is not None else None, bw, nb, chunk_samples, d_R.ptr))
+
+
+def regressor_tsqr_batch(model, mode, flags, ft_mask, B, n_per, d_q, d_v, d_a, d_idx, n, d_R_stack, d_R):
+    """B trajectories of n_per samples (back to back in d_q, d_v, d_a) -> B n x n triangles in d_R."""
+    check(load().figh_regressor_tsqr_batch(model.handle, mode, flags, ft_mask, B, n_per, d_q.ptr, d_v.ptr, d_a.ptr,
+                                           d_idx.ptr if d_idx is not None else None, n,
+                                           d_R_stack.ptr if d_R_stack is not None else None, d_R.ptr))
 
 
 def regressor_gram(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau=None, chunk_samples=0):

@@ -10,6 +10,7 @@
 //   figh_regressor_gram   : W_e^T W_e, W_e^T tau, tau^T tau from that R (host, O(n^3)) -- the normal-equation
 //                           quantities of the SIP QP (identification_tools.py:528-531) and of collective (1) in
 //                           SURVEY.md section 8e, without squaring the condition number on the way.
+#include <algorithm>
 #include <vector>
 
 #include "figh_internal.h"
@@ -158,6 +159,101 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     }
     FIGH_REQUIRE(have < (1LL << 31), "too many level-0 triangles");
     return figh_tsqr_merge(stack, (int)have, nc, d_R_out);
+}
+
+// triangles of the previous trajectories (common) and of trajectory b, interleaved: the stack of the pair level that
+// folds the first into every one of the B results
+__global__ __launch_bounds__(256) void interleave_stack_kernel(const double *__restrict__ common,
+                                                               const double *__restrict__ each, const long tri,
+                                                               const long B, double *__restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= tri * B) return;
+    const long b = e / tri, k = e - b * tri;
+    out[2 * b * tri + k] = common[k];
+    out[(2 * b + 1) * tri + k] = each[e];
+}
+
+extern "C" int figh_regressor_tsqr_batch(figh_model_t model, int mode, int flags, int ft_mask, int64_t B, int64_t n_per,
+                                         const double *d_q, const double *d_v, const double *d_a,
+                                         const int32_t *d_col_idx, int n, const double *d_R_stack, double *d_R_out) {
+    int rps = 0, ncols = 0;
+    if (int rc = figh_regressor_shape(model, mode, flags, &rps, &ncols)) return rc;
+    FIGH_REQUIRE(B >= 1 && n_per >= 1, "figh_regressor_tsqr_batch: at least one trajectory of at least one sample");
+    FIGH_REQUIRE(d_q && d_v && d_a && d_R_out, "NULL device pointer");
+    FIGH_REQUIRE(n >= 1 && (d_col_idx ? n <= ncols : n == ncols) && n <= 512, "bad column count");
+    if (int rc = ensure_device()) return rc;
+    const int nc = n;
+    const size_t tri = (size_t)nc * nc;
+    const int nq = model->host.nq, nv = model->host.nv;
+    const int64_t N_tot = B * n_per;
+    if (nc <= 80 || (int64_t)rps * n_per < 8L * nc) {
+        // register-tile kernel (or trajectories too short to be cut further): a launch pair per trajectory
+        FIGH_REQUIRE(!(flags & FIGH_FLAG_BLOCKED_INPUTS) || n_per % 64 == 0,
+                     "tile-blocked inputs: samples per trajectory must be a multiple of 64");
+        double *pair = d_R_stack ? static_cast<double *>(workspace(sizeof(double) * 2 * tri, 20)) : nullptr;
+        if (d_R_stack && !pair) return FIGH_ERR_ALLOC;
+        if (d_R_stack) FIGH_HIP(hipMemcpyAsync(pair, d_R_stack, sizeof(double) * tri, hipMemcpyDeviceToDevice, stream()));
+        for (int64_t b = 0; b < B; ++b) {
+            double *dst = d_R_stack ? pair + tri : d_R_out + (size_t)b * tri;
+            if (int rc = figh_regressor_tsqr(model, mode, flags, ft_mask, n_per, d_q + b * n_per * nq, d_v + b * n_per * nv,
+                                             d_a + b * n_per * nv, d_col_idx, n, nullptr, nullptr, 0, n_per, dst))
+                return rc;
+            if (d_R_stack)
+                if (int rc = figh_tsqr_merge(pair, 2, nc, d_R_out + (size_t)b * tri)) return rc;
+        }
+        return FIGH_OK;
+    }
+    // ---- blocked kernel: ONE K1 launch over all B * n_per samples (the standard joint-major regressor: trajectory b is the
+    // rps row segments [j N_tot + b n_per, + n_per)), ONE batched level-0 launch (wgs workgroups per trajectory), then
+    // pair levels over the whole stack -- wgs is a power of two, so a pair never straddles two trajectories
+    const bool padded = !(model->is_chain && mode == FIGH_MODE_JOINT_TORQUE) && !(flags & FIGH_FLAG_TX40);
+    const int64_t ldc = padded ? 16 * (int64_t)model->host.nlinks : ncols;
+    FIGH_REQUIRE(ldc < (1L << 21), "figh_tsqr: more than 80 columns need a leading dimension below 2^21 elements");
+    double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * N_tot * ldc, 8));
+    if (!Wc) return FIGH_ERR_ALLOC;
+    int32_t *d_cols = const_cast<int32_t *>(d_col_idx);
+    if (padded) {
+        d_cols = static_cast<int32_t *>(workspace(sizeof(int32_t) * (size_t)n, 9));
+        if (!d_cols) return FIGH_ERR_ALLOC;
+        hipLaunchKernelGGL(pad_columns_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), d_col_idx, n, d_cols);
+        FIGH_HIP(hipGetLastError());
+    }
+    if (int rc = padded ? figh_regressor_build_padded(model, mode, flags, ft_mask, N_tot, d_q, d_v, d_a, Wc, ldc, nullptr)
+                        : figh_regressor_build(model, mode, flags, ft_mask, N_tot, d_q, d_v, d_a, Wc, ldc, nullptr))
+        return rc;
+    const long M = tsqr_wide_tile_rows(nc);
+    const long tiles = rps * ((n_per + M - 1) / M);
+    // workgroups per trajectory: enough in total to fill the chip twice over, a leaf at least four tiles and 4 nc rows tall
+    long cap = std::min<long>({tiles / 4, (long)(rps * n_per) / (4L * nc), std::max<long>(1, 1024 / B)});
+    long wgs = 1;
+    while (2 * wgs <= cap) wgs *= 2;
+    double *stack = static_cast<double *>(workspace(sizeof(double) * tri * (size_t)(B * wgs), 11));
+    if (!stack) return FIGH_ERR_ALLOC;
+    {
+        ProfileScope scope("tsqr_batch");
+        if (int rc = launch_tsqr_wide_batch(Wc, ldc, d_cols, n, nc, B, n_per, rps, N_tot, wgs, stack)) return rc;
+    }
+    const double *cur = stack;
+    int slot = 2;
+    for (long w = wgs; w > 1; w /= 2) {
+        ProfileScope scope("tsqr_reduce");
+        double *dst = (w == 2 && !d_R_stack) ? d_R_out : static_cast<double *>(workspace(sizeof(double) * tri * (size_t)(B * w / 2), slot));
+        if (!dst) return FIGH_ERR_ALLOC;
+        if (int rc = launch_tsqr_wide_pairs(cur, B * w, nc, dst)) return rc;
+        cur = dst;
+        slot = slot == 2 ? 3 : 2;
+    }
+    if (!d_R_stack) {
+        if (cur != d_R_out) FIGH_HIP(hipMemcpyAsync(d_R_out, cur, sizeof(double) * tri * B, hipMemcpyDeviceToDevice, stream()));
+        return FIGH_OK;
+    }
+    double *both = static_cast<double *>(workspace(sizeof(double) * 2 * tri * (size_t)B, 20));
+    if (!both) return FIGH_ERR_ALLOC;
+    hipLaunchKernelGGL(interleave_stack_kernel, dim3((unsigned)((tri * B + 255) / 256)), dim3(256), 0, stream(), d_R_stack, cur,
+                       (long)tri, (long)B, both);
+    FIGH_HIP(hipGetLastError());
+    ProfileScope scope("tsqr_reduce");
+    return launch_tsqr_wide_pairs(both, 2 * B, nc, d_R_out);
 }
 
 extern "C" int figh_regressor_gram(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,

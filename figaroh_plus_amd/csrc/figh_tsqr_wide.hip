@@ -38,9 +38,9 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
 #endif
     const bool ok = wy_dispatch(wy_config(nc), [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
         FIGH_LAUNCH_TIMED((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
-                                          decltype(WPE)::value, decltype(LDSC)::value, false>),
+                                          decltype(WPE)::value, decltype(LDSC)::value, 0>),
                           dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, W, rows, ldw, col_idx, n, tau, d_blkw,
-                          rows_per_blk, Rblk, Rws_out, nc, prof, 0L);
+                          rows_per_blk, Rblk, Rws_out, nc, prof, 0L, 0);
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");

@@ -316,25 +316,33 @@ __device__ __forceinline__ void wy_update_lds_chunk(double *__restrict__ lch, co
 // LDSC: chunk NW * CPW -- one more than the register slots hold -- lives in LDS (16 M doubles) and is updated there by its
 // owner until it becomes the last panel.  For column counts one chunk past a register geometry (TALOS: 21 chunks = 4 x 5
 // + 1) this buys the taller tile of the smaller geometry (64 rows with five slots per wave instead of 48 with six).
-template <int NW, int CPW, int NRC, int WPE, bool LDSC, bool PAIR>
+template <int NW, int CPW, int NRC, int WPE, bool LDSC, int MODE>
 __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__restrict__ W_, const long rows_,
                                                                const long ldw, const int *__restrict__ col_idx,
                                                                const int n, const double *__restrict__ tau,
                                                                const double *__restrict__ blkw, const long rows_per_blk,
                                                                double *__restrict__ Rblk, double *__restrict__ Rout,
                                                                const int nc, long long *__restrict__ prof,
-                                                               const long pair_count) {
+                                                               const long pair_count, const int aux) {
+    // MODE 0: level 0 (rows of one tall matrix, tiles dealt round-robin).  MODE 1 = PAIR, MODE 2 = BATCH, below.
+    constexpr bool PAIR = MODE == 1, BATCH = MODE == 2;
     // PAIR (pair-merge mode).  W_ is a stack of pair_count compact nc x nc triangles (ldw == nc); workgroup b
     // starts from triangle 2b (copied into its packed blocks: absorbing a triangle into an EMPTY one would cost a full
     // factorisation to reproduce it) and absorbs triangle 2b + 1, tile by tile, all tiles its own (tile i of a triangle
     // starts at column 16 NRC i).  A last workgroup without a partner passes its triangle through.
     // PAIR is a template parameter so that the level-0 instantiation is the round-2 code, register for register (as
     // run-time mode the extra scalar state moved the TALOS geometry from 68 to 88 bytes of scratch: level 0 +3.7 %).
-    const double *__restrict__ W = PAIR ? W_ + (2L * blockIdx.x + 1) * nc * nc : W_;
+    // BATCH: B independent matrices in ONE joint-major regressor of B * rows_ samples (one K1 launch): matrix b is the
+    // `aux` row segments [j * rows_per_blk + b * rows_, + rows_), j < aux, of W_ (rows_per_blk = the joint stride = total
+    // samples; no row-block weights in this mode).  pair_count = workgroups per matrix: workgroup (b, l) factors the
+    // tiles l, l + pair_count, ... of matrix b -- tile t = segment t / tps, rows [M (t % tps), ...) of it, the ragged end
+    // of every segment zero-filled by the range check of its own buffer descriptor -- into its own triangle.
+    const long bidx = BATCH ? (long)blockIdx.x / pair_count : 0L;
+    const double *__restrict__ W = PAIR ? W_ + (2L * blockIdx.x + 1) * nc * nc : (BATCH ? W_ + bidx * rows_ * ldw : W_);
     const double *__restrict__ Rinit = PAIR ? W_ + (2L * blockIdx.x) * nc * nc : nullptr;
     const long rows = PAIR ? ((2L * blockIdx.x + 1 < pair_count) ? (long)nc : 0L) : rows_;
-    const long tile0 = PAIR ? 0L : (long)blockIdx.x;
-    const long tstep = PAIR ? 1L : (long)gridDim.x;
+    const long tile0 = PAIR ? 0L : (BATCH ? (long)blockIdx.x - bidx * pair_count : (long)blockIdx.x);
+    const long tstep = PAIR ? 1L : (BATCH ? pair_count : (long)gridDim.x);
     static_assert((NW & (NW - 1)) == 0 && NW >= 2, "NW must be a power of two >= 2");
     static_assert(CPW >= 2, "at least two chunk slots per wave");
     FIGH_PROF_DECL
@@ -419,9 +427,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     // requests for the chunk of slot S_ in the tile at row r0_: RPL independent loads per lane.  The descriptor ends
     // with the matrix, so the rows of a ragged last tile beyond `rows` come back as zeros from the buffer range check
     // -- no second, clamped-and-masked load path (whose 64-bit row arithmetic the compiler hoisted into scratch).
-#define FIGH_WY_LOAD(S_, r0_)                                                                                     \
+#define FIGH_WY_LOAD(S_, r0_, lf_)                                                                                  \
     do {                                                                                                          \
-        const long left_ = rows - (r0_);                                                                          \
+        const long left_ = BATCH ? (lf_) : rows - (r0_);                                                                        \
         if ((S_).wlive) {                                                                                         \
             const long bytes_ = left_ * ldw * 8;                                                                  \
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                 \
@@ -463,22 +471,35 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         Q[NQ - 1].wlive = old_.wlive;                                                  \
         Q[NQ - 1].tlive = old_.tlive;                                                  \
         _Pragma("unroll") for (int rc = 0; rc < NRC; ++rc) Q[NQ - 1].t[rc] = old_.t[rc]; \
-        if (next_full) FIGH_WY_LOAD(Q[NQ - 1], rn_);                                   \
+        if (next_full) FIGH_WY_LOAD(Q[NQ - 1], rn_, leftn);                                \
         front += NW;                                                                   \
     } while (0)
 
-    const long ntiles = (rows + M - 1) / M;
+    const long tps = (rows + M - 1) / M;  // tiles per row segment (BATCH)
+    const long ntiles = BATCH ? tps * aux : tps;
     int parity = 0;
     int front = wave;       // chunk held by F; Q[j] holds front + NW (j + 1)
     bool prefetched = false;  // the queue already holds the coming tile (every chunk retires once per tile)
     for (long t = tile0; t < ntiles; t += tstep, parity ^= 1) {
-        const long r0 = t * M;
-        const long r0n = (t + tstep) * M;
-        const bool next_full = r0n < rows;  // the workgroup has another tile (full or ragged: the descriptor zero-fills)
+        long r0, r0n, left = 0, leftn = 0;
+        bool next_full;  // the workgroup has another tile (full or ragged: the descriptor zero-fills)
+        if constexpr (BATCH) {
+            const long sg = t / tps, tn = t + tstep, sgn = tn / tps;
+            r0 = sg * rows_per_blk + (t - sg * tps) * M;
+            left = rows - (t - sg * tps) * M;
+            r0n = sgn * rows_per_blk + (tn - sgn * tps) * M;
+            leftn = rows - (tn - sgn * tps) * M;
+            next_full = tn < ntiles;
+            asm volatile("" : "+s"(leftn));
+        } else {
+            r0 = t * M;
+            r0n = (t + tstep) * M;
+            next_full = r0n < rows;
+        }
         if (!prefetched) {
-            FIGH_WY_LOAD(F, r0);
+            FIGH_WY_LOAD(F, r0, left);
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) FIGH_WY_LOAD(Q[j], r0);
+            for (int j = 0; j < NQ; ++j) FIGH_WY_LOAD(Q[j], r0, left);
         }
         prefetched = next_full;
         // The LDS chunk is requested at the top of the tile (its LDS home is in use until the tile's last panel) into a
@@ -496,7 +517,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         }
 #pragma unroll
         for (int rc = 0; rc < NRC; ++rc) L.t[rc] = f64x4{0.0, 0.0, 0.0, 0.0};
-        if (lowner) FIGH_WY_LOAD(L, r0);
+        if (lowner) FIGH_WY_LOAD(L, r0, left);
         if (blkw) {  // row-block weights (WLS): row r is scaled by blkw[r / rows_per_blk]
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
@@ -745,7 +766,7 @@ int wy_occupancy() {  // resident workgroups per CU (registers and LDS decide)
     static int nb = 0;
     if (!nb) {
         int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, tsqr_wy_kernel<NW, CPW, NRC, WPE, LDSC, false>, 64 * NW, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, tsqr_wy_kernel<NW, CPW, NRC, WPE, LDSC, 0>, 64 * NW, 0) != hipSuccess ||
             v < 1)
             v = 1;
         nb = v;

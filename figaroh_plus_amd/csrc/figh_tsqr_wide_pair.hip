@@ -48,10 +48,10 @@ int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_
     if (!Rblk) return FIGH_ERR_ALLOC;
     const bool ok = wy_dispatch_pair(wy_config_pair(nc), [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
         hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
-                                           decltype(WPE)::value, decltype(LDSC)::value, true>),
+                                           decltype(WPE)::value, decltype(LDSC)::value, 1>),
                            dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, stream(), stack, (long)nc, (long)nc,
                            (const int *)nullptr, nc, (const double *)nullptr, (const double *)nullptr, 1L, Rblk, Rws_out,
-                           nc, (long long *)nullptr, count);
+                           nc, (long long *)nullptr, count, 0);
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");

@@ -15,7 +15,7 @@ trajectories, and the r x r SVD runs on the host.
 import numpy as np
 
 from .. import _lib
-from .._host import host_tail
+from .._host import host_tail, singular_values_batch
 from .regressor import _samples_to_device, regressor_flags
 
 
@@ -54,3 +54,43 @@ def objective_cond(robot, q, v, a, param, idx_e, idx_base, R_stack=None, couplin
     R = base_regressor_triangle(robot, q, v, a, param, idx_e, idx_base, R_stack, coupling)
     s = np.linalg.svd(R, compute_uv=False)
     return float(s.max() / s.min())
+
+
+def base_regressor_triangles_batch(robot, trajectories, param, idx_e, idx_base, R_stack=None, coupling=False):
+    """R factors (B x r x r) of the base regressors of B trajectories ``[(q_b, v_b, a_b), ...]`` of equal length -- one
+    K1 launch over all samples and one batched TSQR launch (``figh_regressor_tsqr_batch``) instead of B launch pairs."""
+    if len(trajectories) == 0:
+        raise ValueError("no trajectory given")
+    mode, flags, ft_mask = regressor_flags(param, coupling)
+    dm = robot.device_model()
+    _, ncols = dm.shape(mode, flags)
+    cols = base_columns(ncols, idx_e, idx_base)
+    r = len(cols)
+    n_per = len(trajectories[0][0])
+    if n_per == 0 or any(len(t[0]) != n_per or len(t[1]) != n_per or len(t[2]) != n_per for t in trajectories):
+        raise ValueError("the trajectories of a batch must have the same, non-zero number of samples")
+    q = np.concatenate([np.asarray(t[0], dtype=np.float64) for t in trajectories])
+    v = np.concatenate([np.asarray(t[1], dtype=np.float64) for t in trajectories])
+    a = np.concatenate([np.asarray(t[2], dtype=np.float64) for t in trajectories])
+    _, d_q, d_v, d_a = _samples_to_device(robot.model, q, v, a)
+    B = len(trajectories)
+    d_idx = _lib.DeviceArray.from_host(cols)
+    d_stack = None
+    if R_stack is not None:
+        R_stack = np.ascontiguousarray(R_stack, dtype=np.float64)
+        if R_stack.shape != (r, r):
+            raise ValueError("R_stack must be the %d x %d triangle of the previous base regressor" % (r, r))
+        d_stack = _lib.DeviceArray.from_host(np.triu(R_stack).reshape(-1))
+    d_R = _lib.DeviceArray((B * r * r,), np.float64)
+    _lib.regressor_tsqr_batch(dm, mode, flags, ft_mask, B, n_per, d_q, d_v, d_a, d_idx, r, d_stack, d_R)
+    return np.triu(d_R.to_host().reshape(B, r, r))
+
+
+@host_tail
+def objective_cond_batch(robot, trajectories, param, idx_e, idx_base, R_stack=None, coupling=False):
+    """``[np.linalg.cond(W_b) for every trajectory]``: the objective of examples/tiago/optimal_trajectory.py:100-133 at
+    the B perturbed trajectories of one finite-difference gradient (numdifftools around ``objective_func``, :296-313),
+    r x r SVDs batched on the host."""
+    R = base_regressor_triangles_batch(robot, trajectories, param, idx_e, idx_base, R_stack, coupling)
+    s = singular_values_batch(R)
+    return (s.max(axis=1) / s.min(axis=1)).tolist()

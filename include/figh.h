@@ -217,6 +217,15 @@ int figh_regressor_colsq(figh_model_t model, int mode, int flags, int ft_mask, i
 int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
                         const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
                         const double *h_block_weight, int nblocks, int64_t chunk_samples, double *d_R_out);
+/* figh_regressor_tsqr_batch: B independent trajectories of n_per samples each (d_q, d_v, d_a hold the B * n_per samples
+ * back to back) -> B triangles, d_R_out[b] = the n x n R factor of W[:, d_col_idx] of trajectory b.  With d_R_stack (one
+ * n x n triangle, nullable) every result is the R factor of vstack((W_stack, W_b)) instead, R_stack being the triangle
+ * of W_stack.  This is one finite-difference gradient of the excitation objective, np.linalg.cond(W_b) per perturbed
+ * trajectory (examples/tiago/optimal_trajectory.py:100-133, 296-313), in one K1 launch + one batched TSQR launch + the
+ * pair-merge levels for more than 80 columns (trajectory by trajectory through figh_regressor_tsqr otherwise). */
+int figh_regressor_tsqr_batch(figh_model_t model, int mode, int flags, int ft_mask, int64_t B, int64_t n_per,
+                              const double *d_q, const double *d_v, const double *d_a, const int32_t *d_col_idx, int n,
+                              const double *d_R_stack, double *d_R_out);
 /* figh_regressor_gram: h_G = W_e^T W_e (n x n, row-major, host), h_g = W_e^T tau (n), *h_tau_sq = tau^T tau, formed
  * from the Householder R (G = R1^T R1): the normal-equation quantities of the SIP QP (identification_tools.py:528-531)
  * and of the weighted LS statements (staubli_TX40/identification.py:320-327).  h_g / h_tau_sq may be NULL iff d_tau
