@@ -616,19 +616,39 @@ __global__ __launch_bounds__(256) void select_columns_kernel(const double *__res
 __global__ __launch_bounds__(256) void scatter_regrouped_kernel(const double *__restrict__ R, const double *__restrict__ Rr,
                                                                 const int *__restrict__ perm, const int nc, const int n,
                                                                 const double tol, double *__restrict__ out) {
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nc * nc; e += gridDim.x * 256) {
+    if (blockIdx.x == gridDim.x - 1) {
+        // the last block: (tau, tau) = the residual || tau - W1 phi || = what lies below the base rows of the tau column,
+        // summed by the whole block in a fixed order (one thread walking the two columns cost 90 us of dependent loads)
+        if (n != nc - 1) return;
+        __shared__ double part[256];
+        __shared__ int cnt[256];
+        int c = 0;
+        for (int k = threadIdx.x; k < n; k += 256) c += fabs(R[(long)k * nc + k]) > tol;
+        cnt[threadIdx.x] = c;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) cnt[threadIdx.x] += cnt[threadIdx.x + s];
+            __syncthreads();
+        }
+        const int r = cnt[0];
+        double ss = 0.0;
+        for (int k = r + threadIdx.x; k < nc; k += 256) ss += Rr[(long)k * nc + n] * Rr[(long)k * nc + n];
+        part[threadIdx.x] = ss;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(long)perm[nc - 1] * nc + perm[nc - 1]] = sqrt(part[0]);
+        return;
+    }
+    const int nb = gridDim.x - 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nc * nc; e += nb * 256) {
         const int i = e / nc, j = e - i * nc;
         const int pi = perm[i], pj = perm[j];
         const bool base_row = pi >= n || fabs(R[(long)pi * nc + pi]) > tol;  // the tau column is always a pivot
-        double val = (base_row && j >= i) ? Rr[e] : 0.0;
-        if (n == nc - 1 && e == nc * nc - 1) {  // (tau, tau): the residual || tau - W1 phi || = what lies below the base rows
-            int r = 0;
-            for (int k = 0; k < n; ++k) r += fabs(R[(long)k * nc + k]) > tol;
-            double ss = 0.0;
-            for (int k = r; k < nc; ++k) ss += Rr[(long)k * nc + n] * Rr[(long)k * nc + n];
-            val = sqrt(ss);
-        }
-        out[(long)pi * nc + pj] = val;
+        const double val = (base_row && j >= i) ? Rr[e] : 0.0;
+        if (!(n == nc - 1 && e == nc * nc - 1)) out[(long)pi * nc + pj] = val;  // ((tau, tau): the last block's)
         if (i == 0) out[(long)nc * nc + j] = R[(long)j * nc + j];
     }
 }
@@ -1019,7 +1039,7 @@ static int reveal_triangle(const double *d_R, int nc, int n_free, double tol_qr,
     if (int rc = figh_base_permutation(d_R, nc, n_free, tol_qr, perm)) return rc;
     if (int rc = figh_tsqr(d_R, nc, nc, perm, nc, nullptr, nullptr, 0, Rr)) return rc;
     ProfileScope scope("scatter_regrouped");
-    hipLaunchKernelGGL(scatter_regrouped_kernel, dim3(64), dim3(256), 0, stream(), d_R, Rr, perm, nc, n_free, tol_qr,
+    hipLaunchKernelGGL(scatter_regrouped_kernel, dim3(65), dim3(256), 0, stream(), d_R, Rr, perm, nc, n_free, tol_qr,
                        d_rows_out);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;

@@ -64,9 +64,12 @@ def _expressions(params_base, params_regroup, beta, tol_beta=1e-6):
     out = list(params_base)
     beta = np.asarray(beta)
     ii, jj = np.nonzero(~(np.abs(beta) < tol_beta))
-    vals = beta[ii, jj].tolist()
-    for i, j, b in zip(ii.tolist(), jj.tolist(), vals):
-        out[i] = out[i] + (" - " if b < -tol_beta else " + ") + str(abs(b)) + "*" + str(params_regroup[j])
+    vals = beta[ii, jj]
+    neg = (vals < -tol_beta).tolist()
+    mags = np.abs(vals).tolist()
+    names = [str(p) for p in params_regroup]
+    for i, j, m, ng in zip(ii.tolist(), jj.tolist(), mags, neg):
+        out[i] += (" - " if ng else " + ") + str(m) + "*" + names[j]
     return out
 
 
