@@ -388,3 +388,20 @@ int figh_regressor_shape(figh_model_t model, int mode, int flags, int *rows_per_
 }
 
 }  // extern "C"
+
+#ifdef FIGH_ABLATION
+// Ablation build only (libfigh_ab.so, tools/overlap_probe.py): switch the library stream between two streams, so that two
+// entry points can be put in flight side by side, and wait for the whole device.
+extern "C" int figh_ab_stream_select(int k) {
+    static hipStream_t streams[2] = {nullptr, nullptr};
+    if (int rc = figh::ensure_device()) return rc;
+    if (!streams[0]) streams[0] = g_stream;
+    if (k == 1 && !streams[1]) FIGH_HIP(hipStreamCreateWithFlags(&streams[1], hipStreamNonBlocking));
+    g_stream = streams[k ? 1 : 0];
+    return FIGH_OK;
+}
+extern "C" int figh_ab_device_sync(void) {
+    FIGH_HIP(hipDeviceSynchronize());
+    return FIGH_OK;
+}
+#endif

@@ -96,6 +96,7 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
                      const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out);
 // figh_tsqr_wide_pair.hip: one pair-merge level, `count` stacked triangles -> (count + 1) / 2
 int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_out);
+int launch_tsqr_wide_single(const double *W, long rows, long ldw, const int *col_idx, int n, int nc, double *R_out);
 // figh_tsqr_wide_batch.hip: B matrices (row segments of one joint-major regressor) in one launch, wgs triangles each
 int launch_tsqr_wide_batch(const double *W, long ldw, const int *col_idx, int n, int nc, long B, long n_per, int rps,
                            long seg_stride, long wgs, double *Rws_out);

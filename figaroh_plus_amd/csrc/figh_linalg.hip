@@ -1037,7 +1037,10 @@ static int reveal_triangle(const double *d_R, int nc, int n_free, double tol_qr,
     double *Rr = static_cast<double *>(workspace(sizeof(double) * (size_t)nc * nc, 18));
     if (!perm || !Rr) return FIGH_ERR_ALLOC;
     if (int rc = figh_base_permutation(d_R, nc, n_free, tol_qr, perm)) return rc;
-    if (int rc = figh_tsqr(d_R, nc, nc, perm, nc, nullptr, nullptr, 0, Rr)) return rc;
+    {
+        ProfileScope scope("tsqr_regroup");
+        if (int rc = launch_tsqr_wide_single(d_R, nc, nc, perm, nc, nc, Rr)) return rc;
+    }
     ProfileScope scope("scatter_regrouped");
     hipLaunchKernelGGL(scatter_regrouped_kernel, dim3(65), dim3(256), 0, stream(), d_R, Rr, perm, nc, n_free, tol_qr,
                        d_rows_out);

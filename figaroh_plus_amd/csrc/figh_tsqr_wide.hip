@@ -29,6 +29,8 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
     if (!alias_set) {
         const int v = getenv("FIGH_WY_RALIAS") != nullptr;
         hipMemcpyToSymbol(HIP_SYMBOL(g_wy_ralias), &v, sizeof(int));
+        const int o = getenv("FIGH_WY_OFF") ? atoi(getenv("FIGH_WY_OFF")) : 0;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_wy_off), &o, sizeof(int));
         alias_set = true;
     }
     if (want_prof && rows >= 65536) {

@@ -63,6 +63,7 @@ namespace {
 
 #ifdef FIGH_ABLATION
 __device__ int g_wy_ralias = 0;
+__device__ int g_wy_off = 0;  // FIGH_WY_OFF: wave relabelling per workgroup (which SIMD hosts the owner of panel p)
 #endif
 
 constexpr int kLdv = 17;  // LDS row stride of V (doubles): the transposed reads of B -= V Wm hit 16 different banks
@@ -356,7 +357,17 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     __shared__ int fnz[2][NW];
     __shared__ double lch[LDSC ? 16 * M : 8];
     const int lane = threadIdx.x & 63;
+#ifdef FIGH_ABLATION
+    // mode 1: workgroups of the second half of the grid rotated by two waves, 2: by one, 3: odd workgroups by two,
+    // 4: by blockIdx / 8 (the XCD-local index)
+    const int woff_ = g_wy_off == 1 ? (blockIdx.x >= gridDim.x / 2 ? 2 : 0)
+                      : g_wy_off == 2 ? (blockIdx.x >= gridDim.x / 2 ? 1 : 0)
+                      : g_wy_off == 3 ? ((blockIdx.x & 1) ? 2 : 0)
+                      : g_wy_off == 4 ? (int)(blockIdx.x >> 3) : 0;
+    const int wave = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + woff_) & (NW - 1));
+#else
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
     const int c = lane & 15, g = lane >> 4;
     const int nch = (nc + 15) >> 4;
     constexpr int LC = NW * CPW;                               // the chunk that lives in LDS (LDSC)

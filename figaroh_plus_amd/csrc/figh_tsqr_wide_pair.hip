@@ -46,12 +46,39 @@ int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_
     const size_t blk_bytes = sizeof(double) * 256 * ((size_t)nch * (nch + 1) / 2) * (size_t)nwg;
     double *Rblk = static_cast<double *>(workspace(blk_bytes, 13));
     if (!Rblk) return FIGH_ERR_ALLOC;
-    const bool ok = wy_dispatch_pair(wy_config_pair(nc), [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
+    auto launch = [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
         hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
                                            decltype(WPE)::value, decltype(LDSC)::value, 1>),
                            dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, stream(), stack, (long)nc, (long)nc,
                            (const int *)nullptr, nc, (const double *)nullptr, (const double *)nullptr, 1L, Rblk, Rws_out,
                            nc, (long long *)nullptr, count, 0);
+    };
+    // More pairs than CUs (the stacked triangles of a streamed run: 20 chunks x 512 for the human model): the level is
+    // throughput-bound, and the level-0 geometry -- four waves, two workgroups = two chains per CU -- absorbs twice as
+    // many triangles per CU at a time as the eight-wave one (5121 pairs of 191 columns: 4.7 ms with the latter).
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool ok = nwg > cus ? wy_dispatch(wy_config(nc), launch) : wy_dispatch_pair(wy_config_pair(nc), launch);
+    if (!ok) {
+        set_error("figh_tsqr: no wide-kernel geometry for this column count");
+        return FIGH_ERR_UNSUPPORTED;
+    }
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+// One workgroup, one small matrix (rows of the order of nc: the regrouped factorisation qr(R[:, perm]) of the rank step)
+// with the pair-merge geometry -- the same latency-bound situation, eight waves and the tallest tile
+int launch_tsqr_wide_single(const double *W, long rows, long ldw, const int *col_idx, int n, int nc, double *R_out) {
+    const int nch = (nc + 15) >> 4;
+    double *Rblk = static_cast<double *>(workspace(sizeof(double) * 256 * ((size_t)nch * (nch + 1) / 2), 13));
+    if (!Rblk) return FIGH_ERR_ALLOC;
+    const bool ok = wy_dispatch_pair(wy_config_pair(nc), [&](auto NW, auto CPW, auto NRC, auto WPE, auto LDSC) {
+        hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
+                                           decltype(WPE)::value, decltype(LDSC)::value, 0>),
+                           dim3(1), dim3(64 * decltype(NW)::value), 0, stream(), W, rows, ldw, col_idx, n,
+                           (const double *)nullptr, (const double *)nullptr, 1L, Rblk, R_out, nc, (long long *)nullptr, 0L, 0);
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");
