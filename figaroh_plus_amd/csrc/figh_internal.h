@@ -93,7 +93,10 @@ void forget_tapes(const figh_model_s *m);
 // figh_tsqr_wide.hip: the blocked (compact-WY, MFMA) level for nc > 80 columns
 long tsqr_wide_workgroups(int nc, int cus);
 int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
-                     const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out);
+                     const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out, int chain_flags = 0);
+// figh_linalg.hip: the NEXT figh_tsqr_level0 call (more than 80 columns) runs with exactly `wgs` workgroups and these chain
+// flags (launch_tsqr_wide); consumed by that call
+void tsqr_level0_chain(long wgs, int chain_flags);
 // figh_tsqr_wide_pair.hip: one pair-merge level, `count` stacked triangles -> (count + 1) / 2
 int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_out);
 int launch_tsqr_wide_single(const double *W, long rows, long ldw, const int *col_idx, int n, int nc, double *R_out);
@@ -101,6 +104,8 @@ int launch_tsqr_wide_single(const double *W, long rows, long ldw, const int *col
 int launch_tsqr_wide_batch(const double *W, long ldw, const int *col_idx, int n, int nc, long B, long n_per, int rps,
                            long seg_stride, long wgs, double *Rws_out);
 int tsqr_wide_tile_rows(int nc);
+int launch_tsqr_wide_chain(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
+                           const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out);
 
 // figh_tsqr_tree.hip: every merge level of the register-tile TSQR (nc <= 80) in one launch: `count` stacked triangles ->
 // the plain triangle d_out; d_rows_out != nullptr appends the rank decision (columns k < n_free, threshold tol) and the

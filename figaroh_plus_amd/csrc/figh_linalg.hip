@@ -675,6 +675,13 @@ static size_t tsqr2_lds_bytes(int ncc, int nc) {
 // per-tile structure hint of the register-tile kernel: g_tile_hint is installed by figh_tsqr_hint_begin for the level-0
 // launch of the NEXT figh_tsqr_level0 call only (the merge levels run on stacked triangles and never see it)
 static const int *g_tile_hint = nullptr;
+// chained level-0 launches of a streamed run (blocked kernel only): workgroup count and chain flags of the next call
+static long g_chain_wgs = 0;
+static int g_chain_flags = 0;
+void tsqr_level0_chain(long wgs, int chain_flags) {
+    g_chain_wgs = wgs;
+    g_chain_flags = chain_flags;
+}
 
 __global__ __launch_bounds__(256) void tile_hint_kernel(const int *__restrict__ first, const long hint_rows,
                                                         const long rows, const long ntiles, int *__restrict__ out) {
@@ -702,13 +709,15 @@ static const int *zero_tile_hint(long ntiles) {  // "no structure known": first 
 // structure hint of the register-tile kernel, level 0 only (nullptr: none).
 static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
                       const double *d_blkw, long rows_per_blk, int nc, long target_wgs, double *Rws_out, long *nw_out,
-                      const int *hint) {
+                      const int *hint, long chain_wgs = 0, int chain_flags = 0) {
     const long ntiles = (rows + 63) / 64;
     long nw = target_wgs < ntiles ? target_wgs : ntiles;
     if (nw < 1) nw = 1;
+    if (nc > 80 && chain_wgs > 0) nw = chain_wgs;  // chained launches keep their workgroup count (idle ones pass through)
     *nw_out = nw;
     if (nc > 80)
-        return launch_tsqr_wide(W, rows, ldw, col_idx, n, tau, d_blkw, rows_per_blk, nc, nw, Rws_out);
+        return launch_tsqr_wide(W, rows, ldw, col_idx, n, tau, d_blkw, rows_per_blk, nc, nw, Rws_out,
+                                chain_wgs > 0 ? chain_flags : 0);
     // The register-tile kernel deals tile positions p = wave, wave + nw, ... and maps position p to the (p mod 8)-th
     // eighth of the row range (8-way interleave, see the kernel).  With nw a multiple of 8 a wave would stay inside one
     // eighth for its whole life -- in the joint-major row order that is all-heavy (joint 1) or all-light (joint 6) work:
@@ -886,6 +895,10 @@ int figh_block_sqnorm(const double *d_a, const double *d_b, int64_t rows, int nb
 int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n, const double *d_tau,
                      const double *h_block_weight, int nblocks, double *d_tri_out, int64_t capacity, int64_t *count_out,
                      double **ws_out) {
+    const long chain_wgs = g_chain_wgs;  // (consumed by this call whatever its outcome)
+    const int chain_flags = g_chain_flags;
+    g_chain_wgs = 0;
+    g_chain_flags = 0;
     FIGH_REQUIRE(d_W && count_out, "NULL device pointer");
     FIGH_REQUIRE(rows > 0 && n > 0 && ldw > 0, "bad shape");
     const int nc = n + (d_tau ? 1 : 0);
@@ -922,7 +935,7 @@ int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t
         if (cap < 1) cap = 1;
         if (target > cap) target = cap;
     }
-    const long nw_est = target + 1;
+    const long nw_est = (nc > 80 && chain_wgs > target ? chain_wgs : target) + 1;
     double *Rws = d_tri_out;
     if (Rws) {
         FIGH_REQUIRE(capacity >= nw_est, "figh_tsqr_level0: triangle buffer too small");
@@ -935,7 +948,8 @@ int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t
     long nw = 0;
     {
         ProfileScope scope(rows >= 65536 ? "tsqr" : "tsqr_small", true);
-        if (int rc = tsqr_level(d_W, rows, ldw, d_col_idx, n, d_tau, d_blkw, rows_per_blk, nc, target, Rws, &nw, hint))
+        if (int rc = tsqr_level(d_W, rows, ldw, d_col_idx, n, d_tau, d_blkw, rows_per_blk, nc, target, Rws, &nw, hint,
+                                chain_wgs, chain_flags))
             return rc;
     }
     *count_out = nw;

@@ -11,6 +11,7 @@
 //                           quantities of the SIP QP (identification_tools.py:528-531) and of collective (1) in
 //                           SURVEY.md section 8e, without squaring the condition number on the way.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "figh_internal.h"
@@ -136,6 +137,16 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
             }
         }
     }
+    // More than 80 columns and several chunks: CHAINED launches -- every workgroup of the blocked kernel keeps ONE running
+    // triangle across the chunks (same workgroup count in every launch; a launch starts from the triangle the previous one
+    // wrote), so the stack to merge holds one launch's triangles instead of nchunks times as many (human model, 20 chunks:
+    // 512 instead of 10 240 triangles, merges 8.3 -> 1.8 ms).
+#ifdef FIGH_ABLATION
+    const bool chained = nc > 80 && nchunks > 1 && !getenv("FIGH_NO_CHAIN");  // same-box A/B (tools/chain_ab.sh)
+#else
+    const bool chained = nc > 80 && nchunks > 1;
+#endif
+    const long chain_wgs = chained ? std::min<long>(per_chunk - 1, std::max<long>(1, (long)rps * cs / (8L * nc))) : 0;
     int64_t have = 0;
     for (int64_t lo = 0; lo < N; lo += cs) {
         const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
@@ -151,11 +162,12 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
         if (!first.empty() && nc_ >= 64) {
             if (int rc = figh_tsqr_hint_begin(first.data(), rps, (int64_t)rps * nc_, n, nc)) return rc;
         }
+        if (chained) tsqr_level0_chain(chain_wgs, lo > 0 ? 1 : 0);
         const int rc0 = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ldc, d_cols, n, tc, h_block_weight, nblocks,
-                                         stack + (size_t)have * nc * nc, per_chunk, &got, nullptr);
+                                         stack + (size_t)(chained ? 0 : have) * nc * nc, per_chunk, &got, nullptr);
         figh_tsqr_hint_end();
         if (rc0) return rc0;
-        have += got;
+        have = chained ? got : have + got;
     }
     FIGH_REQUIRE(have < (1LL << 31), "too many level-0 triangles");
     return figh_tsqr_merge(stack, (int)have, nc, d_R_out);

@@ -14,9 +14,12 @@ long tsqr_wide_workgroups(const int nc, const int cus) {
     return (long)cus * occ;
 }
 
-// rows of (W, ldw) -> nwg triangles (nc x nc, row-major) in Rws_out; tiles are dealt round-robin to the workgroups
+// rows of (W, ldw) -> nwg triangles (nc x nc, row-major) in Rws_out; tiles are dealt round-robin to the workgroups.
+// chain_flags: bit 0 = the workgroups continue from the triangles Rws_out holds (same nwg and nc as the launch before)
 int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, int n, const double *tau,
-                     const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out) {
+                     const double *d_blkw, long rows_per_blk, int nc, long nwg, double *Rws_out, int chain_flags) {
+    if (chain_flags & 1)  // the CHAIN instantiations live in figh_tsqr_wide_batch.hip
+        return launch_tsqr_wide_chain(W, rows, ldw, col_idx, n, tau, d_blkw, rows_per_blk, nc, nwg, Rws_out);
     const int nch = (nc + 15) >> 4;
     const size_t blk_bytes = sizeof(double) * 256 * ((size_t)nch * (nch + 1) / 2) * (size_t)nwg;
     double *Rblk = static_cast<double *>(workspace(blk_bytes, 13));
@@ -31,6 +34,10 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
         hipMemcpyToSymbol(HIP_SYMBOL(g_wy_ralias), &v, sizeof(int));
         const int o = getenv("FIGH_WY_OFF") ? atoi(getenv("FIGH_WY_OFF")) : 0;
         hipMemcpyToSymbol(HIP_SYMBOL(g_wy_off), &o, sizeof(int));
+        int dm = 0, dt = 0;
+        if (const char *e = getenv("FIGH_WY_DELAY")) sscanf(e, "%d,%d", &dm, &dt);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_wy_delay_mode), &dm, sizeof(int));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_wy_delay_ticks), &dt, sizeof(int));
         alias_set = true;
     }
     if (want_prof && rows >= 65536) {

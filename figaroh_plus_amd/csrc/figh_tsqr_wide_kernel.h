@@ -64,6 +64,7 @@ namespace {
 #ifdef FIGH_ABLATION
 __device__ int g_wy_ralias = 0;
 __device__ int g_wy_off = 0;  // FIGH_WY_OFF: wave relabelling per workgroup (which SIMD hosts the owner of panel p)
+__device__ int g_wy_delay_mode = 0, g_wy_delay_ticks = 0;  // FIGH_WY_DELAY="mode,ticks": start-up delay of some workgroups
 #endif
 
 constexpr int kLdv = 17;  // LDS row stride of V (doubles): the transposed reads of B -= V Wm hit 16 different banks
@@ -340,7 +341,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     // of every segment zero-filled by the range check of its own buffer descriptor -- into its own triangle.
     const long bidx = BATCH ? (long)blockIdx.x / pair_count : 0L;
     const double *__restrict__ W = PAIR ? W_ + (2L * blockIdx.x + 1) * nc * nc : (BATCH ? W_ + bidx * rows_ * ldw : W_);
-    const double *__restrict__ Rinit = PAIR ? W_ + (2L * blockIdx.x) * nc * nc : nullptr;
+    // (MODE 3 = CHAIN, chained level-0 launches: the workgroup's own triangle of the previous launch, read back from Rout;
+    // a mode of its own for the same reason as PAIR: as a run-time flag of MODE 0 it cost the TALOS geometry 20 more
+    // bytes of scratch)
+    constexpr bool CHAIN = MODE == 3;
+    const double *__restrict__ Rinit = PAIR ? W_ + (2L * blockIdx.x) * nc * nc
+                                            : (CHAIN ? Rout + (long)blockIdx.x * nc * nc : nullptr);
     const long rows = PAIR ? ((2L * blockIdx.x + 1 < pair_count) ? (long)nc : 0L) : rows_;
     const long tile0 = PAIR ? 0L : (BATCH ? (long)blockIdx.x - bidx * pair_count : (long)blockIdx.x);
     const long tstep = PAIR ? 1L : (BATCH ? pair_count : (long)gridDim.x);
@@ -391,13 +397,20 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double val = 0.0;
-            if constexpr (PAIR) {
+            if constexpr (PAIR || CHAIN) {
                 const int row = 16 * p + g + 4 * r, col = 16 * cc + c;
                 if (col < nc && row <= col) val = Rinit[(long)row * nc + col];
             }
             b[lane + 64 * r] = val;
         }
     };
+    // CHAIN (chained launches of a streamed run): the workgroup starts from its own triangle of the previous
+    // sample chunk (read back from Rout) -- one RUNNING triangle per workgroup instead of one per workgroup and chunk (the
+    // human model's 20 chunks: 512 triangles to merge instead of 10 240).  Measured on one box (tools/chain_ab.sh): a launch
+    // that starts from a filled triangle takes 7.6 ms where one that starts from zeros takes 7.2 ms, whether the blocks are
+    // left in place or re-created, in or out of phase with the other workgroup of the CU (tools/wydelay_ab.sh) -- the
+    // operands of the first half of a launch (force rows: the inertia columns are exact zeros) are then no longer mostly
+    // zero; the merges saved (8.3 -> 1.8 ms) outweigh it.
     if (lowner)
         for (int p = 0; p <= LC; ++p) init_block(p, LC);
 #pragma unroll
