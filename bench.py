@@ -171,7 +171,7 @@ def main():
                     help="samples of the CPU baseline legs (default: 300000 for cfg2, 20000 for cfg3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
-    ap.add_argument("--placement-trials", type=int, default=4,
+    ap.add_argument("--placement-trials", type=int, default=8,
                     help="set-up (untimed): candidate allocations of W among which the one K1 writes fastest is kept "
                          "(IdentificationPipeline.placement_trials; 1 = take the first)")
     ap.add_argument("--host-wait", default=None, choices=["spin", "block"],

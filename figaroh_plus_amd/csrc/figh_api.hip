@@ -1,5 +1,7 @@
 // Runtime plumbing of libfigh.so: device selection, memory, the library stream, per-kernel event timing
 // and the kinematic-tree handle.  No compute lives here.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -199,7 +201,20 @@ int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes)
 int figh_malloc(void **d_ptr, size_t bytes) {
     FIGH_REQUIRE(d_ptr, "d_ptr is NULL");
     if (int rc = ensure_device()) return rc;
-    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 8);
+    hipError_t e = hipErrorUnknown;
+#ifdef FIGH_ABLATION
+    // FIGH_MALLOC_CONTIG: large buffers from physically contiguous memory (tools/k1_alloc_probe.py: does K1's dependence on
+    // the placement of W go away?)
+    static const bool contig = getenv("FIGH_MALLOC_CONTIG") != nullptr;
+    if (contig && bytes >= (64u << 20)) {
+        e = hipExtMallocWithFlags(d_ptr, bytes, hipDeviceMallocContiguous);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            std::fprintf(stderr, "libfigh: contiguous allocation of %zu bytes failed (%s), plain hipMalloc\n", bytes, hipGetErrorString(e));
+        }
+    }
+#endif
+    if (e != hipSuccess) e = hipMalloc(d_ptr, bytes ? bytes : 8);
     if (e != hipSuccess) {
         set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
         return FIGH_ERR_ALLOC;
