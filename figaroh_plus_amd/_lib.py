@@ -73,6 +73,9 @@ SIGNATURES = {
     "figh_regressor_tsqr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int, C.c_int64,
                                       C.c_void_p]),
+    "figh_regressor_tsqr_norms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, _c_double_p, C.c_int, C.c_int64,
+                                            C.c_void_p, C.c_void_p]),
     "figh_regressor_tsqr_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "figh_regressor_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
@@ -312,14 +315,19 @@ def regressor_colsq(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_colsq, chun
                                       d_colsq.ptr))
 
 
-def regressor_tsqr(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau, block_weight, d_R, chunk_samples=0):
+def regressor_tsqr(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau, block_weight, d_R, chunk_samples=0,
+                   d_colsq=None):
+    """``d_colsq`` (ncols doubles): also diag(W^T W) of all columns from the same pass (figh_regressor_tsqr_norms)."""
     bw, nb = None, 0
     if block_weight is not None:
         bwa = _f64(block_weight)
         bw, nb = bwa.ctypes.data_as(_c_double_p), len(bwa)
-    check(load().figh_regressor_tsqr(model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr,
-                                     d_idx.ptr if d_idx is not None else None, n,
-                                     d_tau.ptr if d_tau is not None else None, bw, nb, chunk_samples, d_R.ptr))
+    args = (model.handle, mode, flags, ft_mask, N, d_q.ptr, d_v.ptr, d_a.ptr, d_idx.ptr if d_idx is not None else None, n,
+            d_tau.ptr if d_tau is not None else None, bw, nb, chunk_samples, d_R.ptr)
+    if d_colsq is not None:
+        check(load().figh_regressor_tsqr_norms(*args, d_colsq.ptr))
+    else:
+        check(load().figh_regressor_tsqr(*args))
 
 
 def regressor_tsqr_batch(model, mode, flags, ft_mask, B, n_per, d_q, d_v, d_a, d_idx, n, d_R_stack, d_R):

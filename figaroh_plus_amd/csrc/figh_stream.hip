@@ -76,10 +76,32 @@ extern "C" int figh_regressor_colsq(figh_model_t model, int mode, int flags, int
     return FIGH_OK;
 }
 
+static int regressor_tsqr_impl(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                               const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
+                               const double *h_block_weight, int nblocks, int64_t chunk_samples, double *d_R_out,
+                               double *d_colsq_out);
+
 extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
                                    const double *d_v, const double *d_a, const int32_t *d_col_idx, int n,
                                    const double *d_tau, const double *h_block_weight, int nblocks, int64_t chunk_samples,
                                    double *d_R_out) {
+    return regressor_tsqr_impl(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_col_idx, n, d_tau, h_block_weight, nblocks,
+                               chunk_samples, d_R_out, nullptr);
+}
+
+extern "C" int figh_regressor_tsqr_norms(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                                         const double *d_v, const double *d_a, const int32_t *d_col_idx, int n,
+                                         const double *d_tau, const double *h_block_weight, int nblocks,
+                                         int64_t chunk_samples, double *d_R_out, double *d_colsq_out) {
+    FIGH_REQUIRE(d_colsq_out, "NULL device pointer");
+    return regressor_tsqr_impl(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_col_idx, n, d_tau, h_block_weight, nblocks,
+                               chunk_samples, d_R_out, d_colsq_out);
+}
+
+static int regressor_tsqr_impl(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                               const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
+                               const double *h_block_weight, int nblocks, int64_t chunk_samples, double *d_R_out,
+                               double *d_colsq_out) {
     int rps = 0, ncols = 0;
     if (int rc = figh_regressor_shape(model, mode, flags, &rps, &ncols)) return rc;
     FIGH_REQUIRE(N >= 0 && chunk_samples >= 0, "negative size");
@@ -88,6 +110,7 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     if (h_block_weight) FIGH_REQUIRE(nblocks > 0 && rps % nblocks == 0, "row-block weights must divide the rows of a sample");
     if (int rc = ensure_device()) return rc;
     const int nc = n + (d_tau ? 1 : 0);
+    if (d_colsq_out) FIGH_HIP(hipMemsetAsync(d_colsq_out, 0, sizeof(double) * ncols, stream()));
     if (N == 0) {
         FIGH_HIP(hipMemsetAsync(d_R_out, 0, sizeof(double) * (size_t)nc * nc, stream()));
         return FIGH_OK;
@@ -95,6 +118,10 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     if (chunk_samples == 0) chunk_samples = default_chunk(rps, ncols);
     const int64_t cs = chunk_samples < N ? chunk_samples : N;
     const int64_t nchunks = (N + cs - 1) / cs;
+    // diag(W^T W) of all columns fused into the regressor kernel of every chunk (the elimination's input, for a caller that
+    // factors the columns it EXPECTS to be kept and verifies the set afterwards: no separate norms pass over the samples)
+    double *cs_part = d_colsq_out ? static_cast<double *>(workspace(sizeof(double) * ncols, 21)) : nullptr;
+    if (d_colsq_out && !cs_part) return FIGH_ERR_ALLOC;
     FIGH_REQUIRE(!(flags & FIGH_FLAG_BLOCKED_INPUTS) || nchunks == 1 || cs % 64 == 0,
                  "tile-blocked inputs: chunk_samples must be a multiple of 64");
     // the chunk's W is a private workspace: tree models get the link-padded layout (16 columns per link, every row
@@ -151,10 +178,14 @@ extern "C" int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int 
     for (int64_t lo = 0; lo < N; lo += cs) {
         const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
         if (int rc = padded ? figh_regressor_build_padded(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv,
-                                                          d_a + lo * nv, Wc, ldc, nullptr)
+                                                          d_a + lo * nv, Wc, ldc, cs_part)
                             : figh_regressor_build(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv,
-                                                   d_a + lo * nv, Wc, ldc, nullptr))
+                                                   d_a + lo * nv, Wc, ldc, cs_part))
             return rc;
+        if (cs_part) {
+            hipLaunchKernelGGL(vec_add_kernel, dim3((ncols + 255) / 256), dim3(256), 0, stream(), d_colsq_out, cs_part, ncols);
+            FIGH_HIP(hipGetLastError());
+        }
         if (d_tau)  // rows j*N + [lo, lo + nc_) of tau -> the chunk's joint-major vector (rows j*nc_ + i)
             FIGH_HIP(hipMemcpy2DAsync(tc, sizeof(double) * nc_, d_tau + lo, sizeof(double) * N, sizeof(double) * nc_, rps,
                                       hipMemcpyDeviceToDevice, stream()));

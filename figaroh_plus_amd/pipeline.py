@@ -199,6 +199,28 @@ class IdentificationPipeline:
             self._dc_colsq = _lib.DeviceArray((ncols,), np.float64)
             self._dc_idx = _lib.DeviceArray((cap,), np.int32)
             self._dc_R = _lib.DeviceArray((cap * cap,), np.float64)
+            self._chunk_kept = None  # (the cached column list lived in the old index buffer)
+        with_tau = self.d_tau is not None
+        d_R = self._dc_R
+        # One pass over the samples when the kept set of the previous pass is known: the chunks are factored over THAT column
+        # list while diag(W^T W) of all columns is accumulated by the same regressor launches (figh_regressor_tsqr_norms), and
+        # the set is verified against the norms afterwards -- the same speculation as run() makes with the column count.
+        # (The norms decide on every rank from the all-reduced sums, so a mismatch sends all ranks to the two-pass form.)
+        cached = getattr(self, "_chunk_kept", None)
+        if cached is not None and cached[0] == ncols:
+            kept = cached[1]
+            n = len(kept)
+            _lib.regressor_tsqr(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._dc_idx, n,
+                                self.d_tau if with_tau else None, None, d_R, chunk_samples=self.chunk_samples,
+                                d_colsq=self._dc_colsq)
+            col_norm = ex.sum_columns(self._dc_colsq, ncols)
+            if np.array_equal(np.flatnonzero(~(col_norm < self.tol_e)), cached[2]):
+                nc = n + (1 if with_tau else 0)
+                idx_e, params_r = list(cached[3]), list(cached[4])
+                d_stack, count = ex.stack_triangles(d_R, nc)
+                return self._tail(d_stack, count, n, nc, params_r, idx_e, col_norm, with_tau,
+                                  rps * self.N * ex.world_size, strings)
+            self._chunk_kept = None  # the kept set changed: two passes, below
         # pass 1: column norms
         _lib.regressor_colsq(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._dc_colsq,
                              chunk_samples=self.chunk_samples)
@@ -207,12 +229,11 @@ class IdentificationPipeline:
         kept = [i for i in range(ncols) if not col_norm[i] < self.tol_e]
         params_r = [self.names[i] for i in kept]
         n = len(kept)
-        with_tau = self.d_tau is not None
         nc = n + (1 if with_tau else 0)
         kept_i32 = np.asarray(kept, dtype=np.int32)
         _lib.check(lib.figh_memcpy_h2d(self._dc_idx.ptr, kept_i32.ctypes.data, kept_i32.nbytes))
+        self._chunk_kept = (ncols, kept, np.asarray(kept, dtype=np.int64), list(idx_e), list(params_r))
         # pass 2: every chunk rebuilt and factored, triangles merged
-        d_R = self._dc_R
         _lib.regressor_tsqr(dm, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, self._dc_idx, n,
                             self.d_tau if with_tau else None, None, d_R, chunk_samples=self.chunk_samples)
         d_stack, count = ex.stack_triangles(d_R, nc)

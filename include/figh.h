@@ -217,6 +217,14 @@ int figh_regressor_colsq(figh_model_t model, int mode, int flags, int ft_mask, i
 int figh_regressor_tsqr(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
                         const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
                         const double *h_block_weight, int nblocks, int64_t chunk_samples, double *d_R_out);
+/* figh_regressor_tsqr_norms: figh_regressor_tsqr that also returns diag(W^T W) of ALL columns (d_colsq_out, ncols doubles,
+ * the reference's numbering) from the same pass -- the norms are fused into the regressor kernel of every chunk.  For a
+ * caller that factors the columns it expects get_index_eliminate (regressor.py:258-279) to keep, e.g. the set of the
+ * previous pass, and verifies the set afterwards: one pass over the samples instead of two. */
+int figh_regressor_tsqr_norms(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
+                              const double *d_v, const double *d_a, const int32_t *d_col_idx, int n, const double *d_tau,
+                              const double *h_block_weight, int nblocks, int64_t chunk_samples, double *d_R_out,
+                              double *d_colsq_out);
 /* figh_regressor_tsqr_batch: B independent trajectories of n_per samples each (d_q, d_v, d_a hold the B * n_per samples
  * back to back) -> B triangles, d_R_out[b] = the n x n R factor of W[:, d_col_idx] of trajectory b.  With d_R_stack (one
  * n x n triangle, nullable) every result is the R factor of vstack((W_stack, W_b)) instead, R_stack being the triangle

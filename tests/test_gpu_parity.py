@@ -532,6 +532,25 @@ def test_chunked_pipeline_equals_one_shot(lib, golden):
     assert out["params_base"] == g.meta["params_base"]
     assert np.abs(out["col_norm"] - g["colsq_big"]).max() <= 1e-12 * g["colsq_big"].max()
     assert np.abs(out["phi_ls"] - g["phi_pinv"]).max() <= 1e-6 * np.abs(g["phi_pinv"]).max()
+    # second pass: ONE pass over the samples -- the kept set of the first pass is factored while the norms of all columns
+    # come out of the same launches, and the set is verified afterwards (figh_regressor_tsqr_norms); same results
+    chunked = pipe._chunked()  # (tile-blocked inputs round the chunk up to whole tiles: 32 TIAGo samples are one chunk)
+    assert not chunked or pipe._chunk_kept is not None
+    out2 = pipe.run()
+    for key in ("idx_e", "idx_base", "params_base", "params_r"):
+        assert out2[key] == out[key]
+    assert np.abs(out2["col_norm"] - out["col_norm"]).max() <= 1e-13 * out["col_norm"].max()
+    assert np.abs(out2["phi_ls"] - out["phi_ls"]).max() <= 1e-12 * np.abs(out["phi_ls"]).max()
+    # a pass whose kept set differs from the cached one (another elimination threshold) notices and takes two passes
+    kept_norms = np.sort(out["col_norm"][out["col_norm"] >= pipe.tol_e])
+    if chunked and len(kept_norms) > 3 and kept_norms[0] < kept_norms[2]:
+        pipe.tol_e = 0.5 * (kept_norms[0] + kept_norms[np.flatnonzero(kept_norms > kept_norms[0])[0]])  # drops the smallest
+        out3 = pipe.run()
+        assert len(out3["idx_e"]) > len(out["idx_e"]) and set(out["idx_e"]) < set(out3["idx_e"])
+        assert len(out3["params_r"]) == len(out["params_r"]) - (len(out3["idx_e"]) - len(out["idx_e"]))
+        out4 = pipe.run()  # and the new set is the cached one from then on
+        assert out4["idx_e"] == out3["idx_e"] and out4["idx_base"] == out3["idx_base"]
+        assert np.abs(out4["phi_ls"] - out3["phi_ls"]).max() <= 1e-12 * max(1.0, np.abs(out3["phi_ls"]).max())
     # synthetic tau built chunk by chunk equals W phi
     pipe2 = IdentificationPipeline(g.robot(), g.param, params_std=g.params_std(), coupling=g.coupling,
                                    chunk_samples=max(7, N // 3 + 1))
