@@ -198,6 +198,10 @@ int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes)
     return FIGH_OK;
 }
 
+#ifdef FIGH_ABLATION
+static std::vector<void *> g_vmm_bases;  // FIGH_MALLOC_VMM probe allocations (left mapped)
+#endif
+
 int figh_malloc(void **d_ptr, size_t bytes) {
     FIGH_REQUIRE(d_ptr, "d_ptr is NULL");
     if (int rc = ensure_device()) return rc;
@@ -214,6 +218,50 @@ int figh_malloc(void **d_ptr, size_t bytes) {
         }
     }
 #endif
+#ifdef FIGH_ABLATION
+    // FIGH_MALLOC_VMM=<chunk MB>[,<order>]: large buffers as one virtual range backed by separately created physical chunks
+    // (order 0: in sequence, 1: reversed) -- does scattering the pages make K1 fast every time?
+    // (never freed: probe only)
+    if (e != hipSuccess && bytes >= (64u << 20)) {
+        if (const char *env = getenv("FIGH_MALLOC_VMM")) {
+            int chunk_mb = 64, order = 0;
+            sscanf(env, "%d,%d", &chunk_mb, &order);
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = dev;
+            size_t gran = 0;
+            hipError_t ve = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+            size_t chunk = (size_t)chunk_mb << 20;
+            if (ve == hipSuccess && gran) chunk = (chunk + gran - 1) / gran * gran;
+            const size_t nchunk = (bytes + chunk - 1) / chunk;
+            void *base = nullptr;
+            if (ve == hipSuccess) ve = hipMemAddressReserve(&base, nchunk * chunk, 0, nullptr, 0);
+            std::vector<hipMemGenericAllocationHandle_t> hs(nchunk);
+            for (size_t k = 0; ve == hipSuccess && k < nchunk; ++k) ve = hipMemCreate(&hs[k], chunk, &prop, 0);
+            for (size_t k = 0; ve == hipSuccess && k < nchunk; ++k) {
+                const size_t src = order == 1 ? nchunk - 1 - k : k;
+                ve = hipMemMap(static_cast<char *>(base) + k * chunk, chunk, 0, hs[src], 0);
+            }
+            if (ve == hipSuccess) {
+                hipMemAccessDesc acc = {};
+                acc.location = prop.location;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                ve = hipMemSetAccess(base, nchunk * chunk, &acc, 1);
+            }
+            if (ve == hipSuccess) {
+                *d_ptr = base;
+                e = hipSuccess;
+                g_vmm_bases.push_back(base);
+            } else {
+                (void)hipGetLastError();
+                std::fprintf(stderr, "libfigh: VMM allocation failed (%s), plain hipMalloc\n", hipGetErrorString(ve));
+            }
+        }
+    }
+#endif
     if (e != hipSuccess) e = hipMalloc(d_ptr, bytes ? bytes : 8);
     if (e != hipSuccess) {
         set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -226,6 +274,10 @@ int figh_free(void *d_ptr) {
     if (!d_ptr) return FIGH_OK;
     if (int rc = ensure_device()) return rc;
     FIGH_HIP(hipStreamSynchronize(g_stream));
+#ifdef FIGH_ABLATION
+    for (void *b : g_vmm_bases)
+        if (b == d_ptr) return FIGH_OK;
+#endif
     FIGH_HIP(hipFree(d_ptr));
     return FIGH_OK;
 }

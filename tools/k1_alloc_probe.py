@@ -13,7 +13,7 @@ mode, flags, ft = regressor_flags(meta['param'], False); dm = robot.device_model
 dq, dv, da = (_lib.DeviceArray.from_host(x.reshape(-1)) for x in (q, v, a))
 dc = _lib.DeviceArray((84,))
 junk = []
-for trial in range(12):
+for trial in range(int(os.environ.get("FIGH_PROBE_TRIALS", "12"))):
     W = _lib.DeviceArray((6 * N * 84,))
     for _ in range(3): _lib.regressor_build(dm, mode, flags, ft, N, dq, dv, da, W, 84, dc)
     _lib.synchronize(); t0 = time.perf_counter()
