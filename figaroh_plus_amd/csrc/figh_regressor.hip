@@ -34,6 +34,7 @@ namespace figh {
 // ---------------------------------------------------------------------------------------------- chain kernel
 #ifdef FIGH_ABLATION
 __device__ int g_chain_hotin = 0;
+__device__ int g_chain_blocked = 0;
 #endif
 
 template <int NJ>
@@ -305,17 +306,29 @@ __global__ __launch_bounds__(64) void regressor_chain_kernel(const ChainParams<N
     long t = blockIdx.x;
     if constexpr (G::VEC == 2) {
         const long nfast = (vec_ok && ldw == NC) ? N / 64 : 0;
-        if (t < nfast) {
+        long tstep = gridDim.x, tend = nfast;
+#ifdef FIGH_ABLATION
+        if (g_chain_blocked) {  // FIGH_K1_BLOCKED: every wave walks its own contiguous range of tiles (tools/k1_alloc_probe.py)
+            const long tpw = (nfast + gridDim.x - 1) / gridDim.x;
+            t = blockIdx.x * tpw;
+            tstep = 1;
+            tend = t + tpw < nfast ? t + tpw : nfast;
+        }
+#endif
+        if (t < tend) {
             fetch_inputs(t);
             // waited for here, outside the loop: a request still pending at the loop header would put a full wait at the
             // top of every iteration
 #pragma unroll
             for (int k = 0; k < NJ; ++k) asm volatile("" : "+v"(pq[k]), "+v"(pqd[k]), "+v"(pqdd[k]));
         }
-        for (; t < nfast; t += gridDim.x) {
-            const long tn = t + gridDim.x;
-            tile_body(std::true_type{}, t, tn < nfast ? tn : t);
+        for (; t < tend; t += tstep) {
+            const long tn = t + tstep;
+            tile_body(std::true_type{}, t, tn < tend ? tn : t);
         }
+#ifdef FIGH_ABLATION
+        if (g_chain_blocked) t = nfast + blockIdx.x;
+#endif
     }
     for (; t < ntiles; t += gridDim.x) {
         fetch_inputs(t);
@@ -397,6 +410,8 @@ static int launch_chain(const figh_model_s *m, int flags, long N, const double *
     {
         const int hot = getenv("FIGH_CHAIN_HOTIN") != nullptr;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_hotin), &hot, sizeof(int));
+        const int blk = getenv("FIGH_K1_BLOCKED") != nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_blocked), &blk, sizeof(int));
     }
 #endif
     ProfileScope scope("regressor_chain", true);
