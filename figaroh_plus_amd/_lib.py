@@ -37,6 +37,8 @@ SIGNATURES = {
     "figh_free": (C.c_int, [C.c_void_p]),
     "figh_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "figh_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "figh_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "figh_host_free": (C.c_int, [C.c_void_p]),
     "figh_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "figh_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "figh_synchronize": (C.c_int, []),
@@ -328,6 +330,28 @@ def regressor_tsqr(model, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_ta
         check(load().figh_regressor_tsqr_norms(*args, d_colsq.ptr))
     else:
         check(load().figh_regressor_tsqr(*args))
+
+
+class PinnedArray:
+    """float64 vector in page-locked host memory (figh_host_alloc); ``.array`` is a NumPy view, valid until ``free``."""
+
+    def __init__(self, n):
+        self._ptr = C.c_void_p()
+        check(load().figh_host_alloc(C.byref(self._ptr), 8 * int(n)))
+        self.size = int(n)
+        self.array = np.ctypeslib.as_array(C.cast(self._ptr, C.POINTER(C.c_double)), shape=(self.size,))
+
+    def free(self):
+        if self._ptr:
+            self.array = None
+            check(load().figh_host_free(self._ptr))
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def regressor_tsqr_batch(model, mode, flags, ft_mask, B, n_per, d_q, d_v, d_a, d_idx, n, d_R_stack, d_R):

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <vector>
 
 #include "figh_internal.h"
@@ -306,9 +307,44 @@ int figh_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes) {
     return FIGH_OK;
 }
 
+// page-locked buffers handed out by figh_host_alloc: copies into them need no staging
+static std::vector<std::pair<char *, size_t>> g_host_bufs;
+
+int figh_host_alloc(void **h_ptr, size_t bytes) {
+    FIGH_REQUIRE(h_ptr, "h_ptr is NULL");
+    if (int rc = ensure_device()) return rc;
+    if (hipHostMalloc(h_ptr, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostMalloc failed");
+        return FIGH_ERR_ALLOC;
+    }
+    g_host_bufs.emplace_back(static_cast<char *>(*h_ptr), bytes ? bytes : 8);
+    return FIGH_OK;
+}
+
+int figh_host_free(void *h_ptr) {
+    if (!h_ptr) return FIGH_OK;
+    for (size_t k = 0; k < g_host_bufs.size(); ++k)
+        if (g_host_bufs[k].first == h_ptr) {
+            g_host_bufs.erase(g_host_bufs.begin() + k);
+            FIGH_HIP(hipStreamSynchronize(g_stream));
+            FIGH_HIP(hipHostFree(h_ptr));
+            return FIGH_OK;
+        }
+    set_error("figh_host_free: not a figh_host_alloc buffer");
+    return FIGH_ERR_INVALID;
+}
+
+static bool is_pinned(const void *p, size_t bytes) {
+    const char *c = static_cast<const char *>(p);
+    for (const auto &b : g_host_bufs)
+        if (c >= b.first && c + bytes <= b.first + b.second) return true;
+    return false;
+}
+
 int figh_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes) {
     if (int rc = ensure_device()) return rc;
-    void *stage = bytes <= kPinnedBytes ? pinned_staging() : nullptr;
+    void *stage = (bytes <= kPinnedBytes && !is_pinned(h_dst, bytes)) ? pinned_staging() : nullptr;
     if (stage) {
         FIGH_HIP(hipMemcpyAsync(stage, d_src, bytes, hipMemcpyDeviceToHost, g_stream));
         FIGH_HIP(hipStreamSynchronize(g_stream));

@@ -298,7 +298,12 @@ class IdentificationPipeline:
                     d_stack, count = ex.stack_triangles(self._d_R, nc)
                     _lib.tsqr_merge_base(d_stack, count, nc, n, self.tol_qr, self._d_rows)
             words = ncols + self._sel_words + ((nc + 1) * nc if n > 0 else 0)
-            host = np.empty(words)
+            # one page-locked landing buffer for the pass's results, reused by every step (everything run() returns is
+            # copied or derived from it before the next step overwrites it)
+            pin = getattr(self, "_host_pack", None)
+            if pin is None or pin.size < self._d_pack.size:
+                pin = self._host_pack = _lib.PinnedArray(self._d_pack.size)
+            host = pin.array[:words]
             _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, self._d_pack.ptr, host.nbytes))
             sel = host[ncols:ncols + self._sel_words].view(np.int32)
             if int(sel[0]) == n:
@@ -364,7 +369,10 @@ class IdentificationPipeline:
         if pack is None or pack.size < (nc + 1) * nc:
             pack = self._d_tailpack = _lib.DeviceArray(((nc + 1) * nc,), np.float64)
         _lib.tsqr_merge_base(d_stack, count, nc, n, self.tol_qr, pack)
-        host = np.empty((nc + 1) * nc)
+        pin = getattr(self, "_host_tailpack", None)
+        if pin is None or pin.size < (nc + 1) * nc:
+            pin = self._host_tailpack = _lib.PinnedArray((nc + 1) * nc)
+        host = pin.array[:(nc + 1) * nc]
         _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, pack.ptr, host.nbytes))
         return self._finish(host.reshape(nc + 1, nc), n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings)
 

@@ -71,6 +71,11 @@ int figh_malloc(void **d_ptr, size_t bytes);
 int figh_free(void *d_ptr);
 int figh_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
 int figh_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+/* Page-locked host memory for results that come back every pass (the (nc + 1) x nc rows of the rank step: 0.9 MB for
+ * TALOS): figh_memcpy_d2h into such a buffer is one DMA, without the staging copy and without first-touch page faults of a
+ * fresh NumPy array.  No reference analogue (the reference's arrays never leave the host). */
+int figh_host_alloc(void **h_ptr, size_t bytes);
+int figh_host_free(void *h_ptr);
 int figh_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes);
 int figh_memset(void *d_dst, int value, size_t bytes);
 int figh_synchronize(void);
