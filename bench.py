@@ -332,6 +332,15 @@ def main():
             roof["tsqr"]["pipe"] = ("fp64 matrix pipe: 16-column panels on the VALU, compact-WY trailing updates as "
                                     "v_mfma_f64_16x16x4 (figh_tsqr_wide.hip); rows whose leading columns are zero start "
                                     "at their first non-zero column, so the executed flops are below the dense 2 m n^2")
+            if getattr(pipe, "_wrench_split", False) and getattr(pipe, "_nf_expected", 0) > 0:
+                # external wrench on a free-flyer root: the three force row blocks are factored over the nf columns that
+                # can be non-zero there (figh_tsqr_selected_wrench) -- `achieved` above counts the reference's dense
+                # 2 m n^2, the flops this path is asked to execute are fewer
+                nf = pipe._nf_expected
+                roof["tsqr"]["executed_flops_per_sample"] = int(3 * 2 * (nf + 1) ** 2 + 3 * 2 * (n_kept + 1) ** 2)
+                roof["tsqr"]["executed_TFLOPs"] = roof["tsqr"]["executed_flops_per_sample"] * N / sec / 1e12
+                roof["tsqr"]["frac_executed"] = roof["tsqr"]["executed_TFLOPs"] / FP64_PEAK_TFLOPS
+                roof["tsqr"]["launches_per_step"] = launches_per_step["tsqr"]
     # HBM bytes per launch: PMC counters cannot be read from inside the process -- the number below comes from the
     # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
     # tools/pmc_summary.py), i.e. from the builder's run, not from this one

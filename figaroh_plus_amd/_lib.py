@@ -66,6 +66,8 @@ SIGNATURES = {
                                        C.c_int, _c_int32_p, C.c_int, C.c_void_p]),
     "figh_tsqr_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "figh_select_columns": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "figh_tsqr_selected_wrench": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_merge_base": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
@@ -405,6 +407,15 @@ def tsqr_selected(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, nblocks, n
     check(load().figh_tsqr_selected(d_W.ptr, rows, ldw, d_colsq.ptr, ncols, tol_e, link_stride, nblocks, n_expected,
                                     d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr,
                                     d_R.ptr if d_R is not None else None))
+
+
+def tsqr_selected_wrench(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_expected, nf_expected, d_tau, tol_qr, d_sel,
+                         d_R):
+    """tsqr_selected for the external-wrench regressor of a free-flyer model: force rows over the ``nf_expected`` kept
+    columns that can be non-zero there, torque rows chained onto their triangle (figh.h)."""
+    check(load().figh_tsqr_selected_wrench(d_W.ptr, rows, ldw, d_colsq.ptr, ncols, tol_e, link_stride, n_expected,
+                                           nf_expected, d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr,
+                                           d_R.ptr if d_R is not None else None))
 
 
 def tsqr_merge_base(d_Rs, count, nc, n_free, tol_qr, d_Rk):

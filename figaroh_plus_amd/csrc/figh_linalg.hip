@@ -610,6 +610,43 @@ __global__ __launch_bounds__(256) void select_columns_kernel(const double *__res
     }
 }
 
+// External-wrench regressor of a free-flyer model: in the three FORCE row blocks the six rotational-inertia columns of
+// every link are exact zeros (a force does not depend on the rotational inertia; the kernel writes J_a = 0 for those
+// rows).  From the kept list (device column numbering, `n` entries) the columns that can be non-zero in force rows --
+// slot >= 6 within a link: mx my mz m, Ia fv fs off -- and their positions in the kept list.  fsel: [n entries: columns]
+// [n entries: positions]; the count is a pure function of the kept mask, the host derives the same number from it.
+__global__ __launch_bounds__(256) void split_force_columns_kernel(const int *__restrict__ kept, const int n,
+                                                                  const int link_stride, int *__restrict__ fsel) {
+    __shared__ int flag[1024];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < n; c += 256) flag[c] = (kept[c] % link_stride) >= 6;
+    __syncthreads();
+    for (int c = tid; c < n; c += 256) {
+        if (!flag[c]) continue;
+        int pos = 0;
+        for (int e = 0; e < c; ++e) pos += flag[e];
+        fsel[pos] = kept[c];
+        fsel[n + pos] = c;
+    }
+}
+
+// The force rows' triangle Rf (ncf x ncf over the force columns [+ tau]) as an nc x nc triangle over ALL kept columns
+// [+ tau]: row r keeps its place, column c moves to the position of force column c in the kept list (tau stays last).
+// Still upper triangular (the position of force column r is >= r); the other entries are zero.
+__global__ __launch_bounds__(1024) void embed_force_triangle_kernel(const double *__restrict__ Rf, const int ncf,
+                                                                    const int nf, const int *__restrict__ fpos,
+                                                                    const int nc, const int n, double *__restrict__ out) {
+    // one workgroup: zero fill, then the scatter
+    for (int e = threadIdx.x; e < nc * nc; e += 1024) out[e] = 0.0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < ncf * ncf; e += 1024) {
+        const int r = e / ncf, c = e - r * ncf;
+        if (c < r) continue;
+        const int col = c < nf ? fpos[c] : n;  // (c == nf: the tau column)
+        out[(long)r * nc + col] = Rf[e];
+    }
+}
+
 // Regrouped triangle -> the layout the regrouping phase of figh_tsqr_tree.hip produces: rows of qr([W1 W2 tau]) in the
 // original column order under their base column, rows of dependent columns zero, then one more row with the diagonal of
 // the plain factorisation.  Wide matrices only (nc > 80).
@@ -1116,6 +1153,70 @@ int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const doubl
     g_tile_hint = nullptr;
     if (rc0) return rc0;
     return reduce_stack(Rws, nw, nc, n_expected, tol_qr, d_R_out);
+}
+
+// figh_tsqr_selected for the external-wrench regressor of a free-flyer model (six row blocks of rows / 6 rows: three force
+// components, three torque components): the force rows are factored over the `nf_expected` kept columns that can be
+// non-zero there (split_force_columns_kernel) -- 2 m nf^2 instead of 2 m n^2 flops for half of the rows -- their triangle
+// is embedded into the full column set and joins the stack of the torque rows' triangles: R is the R factor of the whole
+// W, at 0.5 (1 + (nf / n)^2) of the flops (TALOS, human: 58 %).
+int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                              int link_stride, int n_expected, int nf_expected, const double *d_tau, double tol_qr,
+                              int32_t *d_sel, double *d_R_out) {
+    const int nc = n_expected + (d_tau ? 1 : 0);
+    // no split: unknown counts, the register-tile kernel's column range (no chained form), nothing to gain, odd shapes
+    if (n_expected <= 0 || nf_expected <= 0 || nf_expected >= n_expected || nc <= 80 || rows % 6 != 0 ||
+        rows / 2 < 16L * nc)
+        return figh_tsqr_selected(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, 0, n_expected, d_tau, tol_qr, d_sel,
+                                  d_R_out);
+    FIGH_REQUIRE(d_W && d_colsq && d_sel && d_R_out, "NULL device pointer");
+    FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
+    FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
+    FIGH_REQUIRE(n_expected <= ncols, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    {
+        ProfileScope scope("select_columns");
+        hipLaunchKernelGGL(select_columns_kernel, dim3(1), dim3(256), 0, stream(), d_colsq, ncols, tol_e, link_stride, 0,
+                           (long)rows, 1L, 0L, d_sel, (int *)nullptr);
+        FIGH_HIP(hipGetLastError());
+    }
+    const int n = n_expected, nf = nf_expected, ncf = nf + (d_tau ? 1 : 0);
+    int *fsel = static_cast<int *>(workspace(sizeof(int) * 2 * (size_t)n, 22));
+    if (!fsel) return FIGH_ERR_ALLOC;
+    hipLaunchKernelGGL(split_force_columns_kernel, dim3(1), dim3(256), 0, stream(), d_sel + 2, n, link_stride, fsel);
+    FIGH_HIP(hipGetLastError());
+    const int64_t rows_f = rows / 2;
+    // ---- force rows: their own TSQR over nf columns, reduced to one triangle
+    const int64_t cap_f = figh_tsqr_level0_capacity(ncf);
+    double *tri_f = static_cast<double *>(workspace(sizeof(double) * (size_t)ncf * ncf * cap_f, 23));
+    double *Rf = static_cast<double *>(workspace(sizeof(double) * (size_t)ncf * ncf, 24));
+    if (!tri_f || !Rf) return FIGH_ERR_ALLOC;
+    int64_t cnt_f = 0;
+    if (int rc = figh_tsqr_level0(d_W, rows_f, ldw, fsel, nf, d_tau, nullptr, 0, tri_f, cap_f, &cnt_f, nullptr)) return rc;
+    if (cnt_f == 1) FIGH_HIP(hipMemcpyAsync(Rf, tri_f, sizeof(double) * (size_t)ncf * ncf, hipMemcpyDeviceToDevice, stream()));
+    else if (int rc = tsqr_reduce(tri_f, cnt_f, ncf, Rf)) return rc;
+    // ---- torque rows: chained launch, workgroup 0 starts from the embedded force triangle, the others from zeros
+    long wgs = tsqr_wide_workgroups(nc, cu_count());
+    {
+        long cap = (rows - rows_f) / (8L * nc);
+        if (cap < 1) cap = 1;
+        if (wgs > cap) wgs = cap;
+    }
+    // (the embedded triangle joins the stack as one more element.  Chaining the torque launch onto it -- workgroup 0 starts
+    // from it, no extra element -- was measured first: the CHAIN instantiation of the TALOS geometry carries 180 bytes of
+    // scratch against the plain one's 68 and ran the torque rows in 105.6 ms)
+    const size_t tri = sizeof(double) * (size_t)nc * nc;
+    double *stack = static_cast<double *>(workspace(tri * (size_t)(wgs + 3), 5));
+    if (!stack) return FIGH_ERR_ALLOC;
+    int64_t cnt = 0;
+    if (wgs > 64) tsqr_level0_chain(wgs - 1, 0);  // one workgroup less: with the embedded triangle the stack is 2^k again
+    if (int rc = figh_tsqr_level0(d_W + rows_f * ldw, rows - rows_f, ldw, d_sel + 2, n, d_tau ? d_tau + rows_f : nullptr,
+                                  nullptr, 0, stack, wgs + 2, &cnt, nullptr))
+        return rc;
+    hipLaunchKernelGGL(embed_force_triangle_kernel, dim3(1), dim3(1024), 0, stream(), Rf, ncf, nf, fsel + n, nc, n,
+                       stack + (size_t)cnt * nc * nc);
+    FIGH_HIP(hipGetLastError());
+    return reduce_stack(stack, cnt + 1, nc, n, tol_qr, d_R_out);
 }
 
 int figh_tsqr_merge_base(const double *d_Rs, int count, int nc, int n_free, double tol_qr, double *d_Rk_out) {

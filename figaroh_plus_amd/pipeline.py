@@ -276,6 +276,13 @@ class IdentificationPipeline:
             m = self.robot.model
             structured = mode == _lib.MODE_JOINT_TORQUE and m.nv == m.njoints - 1 and self.N >= 64
             self._hint_blocks = m.nv if structured else 0
+            # external wrench on a free-flyer root: six row blocks, and in the three force blocks the rotational-inertia
+            # columns of every link are exact zeros -- figh_tsqr_selected_wrench factors those rows over the other
+            # columns only (the count of such kept columns is derived from the kept mask, like the column count)
+            from .model import JT_FREEFLYER
+            self._wrench_split = (mode == _lib.MODE_EXT_WRENCH and rows_per_sample == 6 and len(m.joints) > 1 and
+                                  m.joints[1].jtype == JT_FREEFLYER and not self.coupling)
+            self._nf_expected = -1
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
         if self._padded:
             _lib.regressor_build_padded(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld,
@@ -285,15 +292,19 @@ class IdentificationPipeline:
         ex.sum_columns_device(d_colsq, W.ref_cols)
         ncols, with_tau = W.ref_cols, self.d_tau is not None
         stride = 16 if self._padded else 14
-        for attempt in range(3):
+        split = getattr(self, "_wrench_split", False)
+        for attempt in range(4):
             n = self._n_expected
+            nf = self._nf_expected if split else 0
             nc = n + (1 if with_tau else 0)
-            if not getattr(ex, "collective", True):
-                _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
-                                   self.tol_qr, self._d_sel, self._d_rows)
+            local = not getattr(ex, "collective", True)
+            if split:
+                _lib.tsqr_selected_wrench(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, nf, self.d_tau,
+                                          self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
             else:
                 _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
-                                   -1.0, self._d_sel, self._d_R)
+                                   self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
+            if not local:
                 if n > 0:
                     d_stack, count = ex.stack_triangles(self._d_R, nc)
                     _lib.tsqr_merge_base(d_stack, count, nc, n, self.tol_qr, self._d_rows)
@@ -306,9 +317,13 @@ class IdentificationPipeline:
             host = pin.array[:words]
             _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, self._d_pack.ptr, host.nbytes))
             sel = host[ncols:ncols + self._sel_words].view(np.int32)
-            if int(sel[0]) == n:
+            nf_now = 0
+            if split:  # kept columns that can be non-zero in force rows: slot >= 6 within the link
+                nf_now = int(np.count_nonzero(sel[2 + ncols:2 + 2 * ncols][self._force_slots(ncols)]))
+            if int(sel[0]) == n and nf_now == nf:
                 break
             self._n_expected = int(sel[0])  # first pass, or the kept set changed size: solve again with the right shape
+            self._nf_expected = nf_now
             if self._n_expected == 0:
                 raise ValueError("every column of the regressor was eliminated")
         else:
@@ -325,6 +340,13 @@ class IdentificationPipeline:
             self._kept_cache = (kept_mask.copy(), list(idx_e), list(params_r))
         rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
         return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+
+    def _force_slots(self, ncols):
+        """Mask over the reference's columns: slot >= 6 within a link (mx my mz m Ia fv fs off)."""
+        m = getattr(self, "_force_slot_mask", None)
+        if m is None or len(m) != ncols:
+            m = self._force_slot_mask = (np.arange(ncols) % 14) >= 6
+        return m
 
     def device_columns(self, ref_cols):
         """Column indices of the HBM-resident ``self.W`` that hold the reference's columns ``ref_cols`` (trees keep W

@@ -202,6 +202,16 @@ int figh_select_columns(const double *d_colsq, int ncols, double tol_e, int link
 int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                        int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
                        double *d_R_out);
+/* figh_tsqr_selected for the external-wrench regressor of a model with a free-flyer root (regressor.py:89-192: six row
+ * blocks of rows / 6 rows, force components first): in the force rows the six rotational-inertia columns of every link
+ * are exact zeros, so those rows are factored over the nf_expected kept columns with slot >= 6 only (2 m nf^2 instead of
+ * 2 m n^2 flops for half of W), and the torque rows by a launch whose first workgroup starts from the force rows'
+ * triangle.  Same outputs as figh_tsqr_selected (R is the R factor of the whole W[:, kept | tau]); nf_expected is the
+ * number of kept columns c with c % 14 >= 6 -- the caller derives it from the same mask as n_expected and verifies both
+ * afterwards.  nf_expected <= 0, at most 80 columns or rows % 6 != 0: plain figh_tsqr_selected. */
+int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                              int link_stride, int n_expected, int nf_expected, const double *d_tau, double tol_qr,
+                              int32_t *d_sel, double *d_R_out);
 /* figh_tsqr_merge followed by the rank decision and the regrouped factorisation as in figh_tsqr_selected (the cross-rank
  * reduction of the all-gathered per-rank triangles): columns k < n_free take part in the rank decision, the others (tau)
  * always count as base columns.  d_rows_out: (nc + 1) x nc. */

@@ -561,6 +561,54 @@ def test_chunked_pipeline_equals_one_shot(lib, golden):
     assert np.abs(tau - W @ phi).max() <= 1e-11 * max(1.0, np.abs(W @ phi).max())
 
 
+@pytest.mark.parametrize("cfg,model", [("cfg4_talos", "talos"), ("cfg5_human", "human")])
+def test_wrench_force_rows_split(lib, cfg, model):
+    """External wrench on a free-flyer root: (i) the rotational-inertia columns are EXACT zeros in the three force row
+    blocks -- the assumption figh_tsqr_selected_wrench rests on; (ii) the pass that factors the force rows over the
+    remaining columns only and chains the torque rows onto their triangle gives the results of the plain pass."""
+    import json
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic
+    from figaroh_plus_amd.tools.robot import Robot
+    root = os.path.dirname(__file__)
+    meta = json.load(open(os.path.join(root, "golden", cfg + ".json")))
+    robot = Robot.from_flat(model)
+    rng = np.random.default_rng(11)
+    q, v, a = sample_inputs(robot.model, 300, rng, 1.5, 2, 5)
+    W = build_regressor_basic(robot, q, v, a, meta["param"])
+    N = len(q)
+    inertia = (np.arange(W.shape[1]) % 14) < 6
+    assert not W[:3 * N][:, inertia].any()            # force rows: no dependence on the rotational inertia
+    assert np.abs(W[3 * N:][:, inertia]).max() > 0.0  # torque rows do depend on it
+    q, v, a = sample_inputs(robot.model, 6000, rng, 1.5, 2, 5)
+    outs = []
+    for split in (True, False):
+        pipe = IdentificationPipeline(robot, meta["param"], params_std=dict(zip(meta["names_std"], meta["phi_ref_raw"])))
+        pipe.set_samples(q, v, a)
+        pipe.set_tau_from_parameters(np.array([float(x) for x in meta["phi_ref_raw"]]), noise_std=0.01, seed=3)
+        out = pipe.run()
+        if not split:
+            pipe._wrench_split = False
+            pipe._nf_expected = -1
+            out = pipe.run()
+        else:
+            assert pipe._wrench_split and 0 < pipe._nf_expected < pipe._n_expected
+            out = pipe.run()  # (a second pass: counts known from the start)
+        outs.append(out)
+    a_, b_ = outs
+    assert a_["idx_e"] == b_["idx_e"] and a_["idx_base"] == b_["idx_base"] and a_["params_base"] == b_["params_base"]
+    # |R_kk| is implementation independent up to the first dependent column only (behind it the reflector of a dependent
+    # column points along rounding noise, see test_merge_base_rank_revealing_level); dependent pivots sit at roundoff
+    n = len(a_["absdiagR"])
+    rest = sorted(set(range(n)) - set(a_["idx_base"]))
+    first_dep = rest[0] if rest else n
+    assert np.abs(a_["absdiagR"] - b_["absdiagR"])[:first_dep].max() <= 1e-10 * b_["absdiagR"].max()
+    assert a_["absdiagR"][rest].max(initial=0.0) <= 1e-9 * a_["absdiagR"].max()
+    assert np.abs(a_["phi_ls"] - b_["phi_ls"]).max() <= 1e-8 * max(1.0, np.abs(b_["phi_ls"]).max())
+    assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * max(1.0, b_["residual_norm"])
+
+
 def test_tx40_real_data_known_answers_hip(lib):
     """Same known-answer replay with the HIP path end to end: Butterworth filtfilt of the joint positions on the
     device, K1 on the 44 958 real samples, two decimate-by-10 stages of every column of W and of tau on the device,
