@@ -97,6 +97,10 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
 // figh_linalg.hip: the NEXT figh_tsqr_level0 call (more than 80 columns) runs with exactly `wgs` workgroups and these chain
 // flags (launch_tsqr_wide); consumed by that call
 void tsqr_level0_chain(long wgs, int chain_flags);
+// figh_linalg.hip, external wrench on a free-flyer root (figh_tsqr_selected_wrench): the kept columns that can be non-zero
+// in force rows (d_fsel: n columns, then n positions in the kept list) and the force rows' triangle over all kept columns
+int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel);
+int embed_force_triangle(const double *d_Rf, int ncf, int nf, const int *d_fpos, int nc, int n, double *d_out);
 // figh_tsqr_wide_pair.hip: one pair-merge level, `count` stacked triangles -> (count + 1) / 2
 int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_out);
 int launch_tsqr_wide_single(const double *W, long rows, long ldw, const int *col_idx, int n, int nc, double *R_out);

@@ -647,6 +647,17 @@ __global__ __launch_bounds__(1024) void embed_force_triangle_kernel(const double
     }
 }
 
+int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel) {
+    hipLaunchKernelGGL(split_force_columns_kernel, dim3(1), dim3(256), 0, stream(), d_kept, n, link_stride, d_fsel);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+int embed_force_triangle(const double *d_Rf, int ncf, int nf, const int *d_fpos, int nc, int n, double *d_out) {
+    hipLaunchKernelGGL(embed_force_triangle_kernel, dim3(1), dim3(1024), 0, stream(), d_Rf, ncf, nf, d_fpos, nc, n, d_out);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
 // Regrouped triangle -> the layout the regrouping phase of figh_tsqr_tree.hip produces: rows of qr([W1 W2 tau]) in the
 // original column order under their base column, rows of dependent columns zero, then one more row with the diagonal of
 // the plain factorisation.  Wide matrices only (nc > 80).

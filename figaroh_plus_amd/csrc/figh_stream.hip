@@ -173,8 +173,39 @@ static int regressor_tsqr_impl(figh_model_t model, int mode, int flags, int ft_m
 #else
     const bool chained = nc > 80 && nchunks > 1;
 #endif
-    const long chain_wgs = chained ? std::min<long>(per_chunk - 1, std::max<long>(1, (long)rps * cs / (8L * nc))) : 0;
-    int64_t have = 0;
+    // External wrench on a free-flyer root: per chunk the three force row blocks are factored over the nf columns that can
+    // be non-zero there (rotational-inertia columns are exact zeros in force rows, figh_tsqr_selected_wrench) and reduced to
+    // one triangle per chunk; the torque row blocks go through the (chained) launches over all columns.
+    int nf = 0;
+    if (mode == FIGH_MODE_EXT_WRENCH && rps == 6 && model->host.njoints > 1 && model->host.jtype[1] == FIGH_JT_FREEFLYER &&
+        !(flags & FIGH_FLAG_TX40) && !h_block_weight && nc > 80 && 3 * cs >= 16L * nc) {
+        std::vector<int32_t> cols(n);
+        if (d_col_idx) {
+            if (int rc = figh_memcpy_d2h(cols.data(), d_col_idx, sizeof(int32_t) * n)) return rc;
+        } else {
+            for (int c = 0; c < n; ++c) cols[c] = c;
+        }
+        for (int c = 0; c < n; ++c) nf += (cols[c] % 14) >= 6;
+        if (nf >= n) nf = 0;
+    }
+    const bool split = nf > 0;
+    const int ncf = nf + (d_tau ? 1 : 0);
+    const long rsplit = split ? 2 : 1;  // the torque rows are half of a chunk
+    int *fsel = nullptr;
+    double *tri_f = nullptr, *stack_f = nullptr, *Rf = nullptr;
+    int64_t cap_f = 0;
+    if (split) {
+        cap_f = figh_tsqr_level0_capacity(ncf);
+        fsel = static_cast<int *>(workspace(sizeof(int) * 2 * (size_t)n, 22));
+        tri_f = static_cast<double *>(workspace(sizeof(double) * (size_t)ncf * ncf * cap_f, 23));
+        stack_f = static_cast<double *>(workspace(sizeof(double) * (size_t)ncf * ncf * nchunks, 25));
+        Rf = static_cast<double *>(workspace(sizeof(double) * (size_t)ncf * ncf, 24));
+        if (!fsel || !tri_f || !stack_f || !Rf) return FIGH_ERR_ALLOC;
+        if (int rc = split_force_columns(d_cols, n, padded ? 16 : 14, fsel)) return rc;
+    }
+    const long chain_wgs =
+        chained ? std::min<long>(per_chunk - 1, std::max<long>(1, (long)rps * cs / rsplit / (8L * nc))) : 0;
+    int64_t have = 0, kchunk = 0;
     for (int64_t lo = 0; lo < N; lo += cs) {
         const int64_t nc_ = (lo + cs <= N) ? cs : N - lo;
         if (int rc = padded ? figh_regressor_build_padded(model, mode, flags, ft_mask, nc_, d_q + lo * nq, d_v + lo * nv,
@@ -193,14 +224,27 @@ static int regressor_tsqr_impl(figh_model_t model, int mode, int flags, int ft_m
         if (!first.empty() && nc_ >= 64) {
             if (int rc = figh_tsqr_hint_begin(first.data(), rps, (int64_t)rps * nc_, n, nc)) return rc;
         }
+        const int64_t rows_f = split ? 3 * nc_ : 0;  // the chunk's force rows (row blocks 0 .. 2 of its joint-major W)
+        if (split) {
+            int64_t cnt_f = 0;
+            if (int rc = figh_tsqr_level0(Wc, rows_f, ldc, fsel, nf, tc, nullptr, 0, tri_f, cap_f, &cnt_f, nullptr)) return rc;
+            if (int rc = figh_tsqr_merge(tri_f, (int)cnt_f, ncf, stack_f + (size_t)kchunk * ncf * ncf)) return rc;
+        }
         if (chained) tsqr_level0_chain(chain_wgs, lo > 0 ? 1 : 0);
-        const int rc0 = figh_tsqr_level0(Wc, (int64_t)rps * nc_, ldc, d_cols, n, tc, h_block_weight, nblocks,
+        const int rc0 = figh_tsqr_level0(Wc + rows_f * ldc, (int64_t)rps * nc_ - rows_f, ldc, d_cols, n,
+                                         tc ? tc + rows_f : nullptr, h_block_weight, nblocks,
                                          stack + (size_t)(chained ? 0 : have) * nc * nc, per_chunk, &got, nullptr);
         figh_tsqr_hint_end();
         if (rc0) return rc0;
         have = chained ? got : have + got;
+        ++kchunk;
     }
     FIGH_REQUIRE(have < (1LL << 31), "too many level-0 triangles");
+    if (split) {  // the force rows' triangle of all chunks, over all kept columns, as one more element of the stack
+        if (int rc = figh_tsqr_merge(stack_f, (int)kchunk, ncf, Rf)) return rc;
+        if (int rc = embed_force_triangle(Rf, ncf, nf, fsel + n, nc, n, stack + (size_t)have * nc * nc)) return rc;
+        ++have;
+    }
     return figh_tsqr_merge(stack, (int)have, nc, d_R_out);
 }
 
