@@ -68,6 +68,9 @@ SIGNATURES = {
     "figh_select_columns": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "figh_tsqr_selected_wrench": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "figh_tsqr_selected_blocks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                            C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_merge_base": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
@@ -416,6 +419,16 @@ def tsqr_selected_wrench(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_e
     check(load().figh_tsqr_selected_wrench(d_W.ptr, rows, ldw, d_colsq.ptr, ncols, tol_e, link_stride, n_expected,
                                            nf_expected, d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr,
                                            d_R.ptr if d_R is not None else None))
+
+
+def tsqr_selected_blocks(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_expected, counts, d_cols, d_pos, d_tau,
+                         tol_qr, d_sel, d_R):
+    """tsqr_selected with one column list per row block (joint-torque regressor of a tree, figh.h); ``counts``: int32
+    host array, one entry per row block."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    check(load().figh_tsqr_selected_blocks(d_W.ptr, rows, ldw, d_colsq.ptr, ncols, tol_e, link_stride, n_expected,
+                                           len(counts), counts.ctypes.data, d_cols.ptr, d_pos.ptr,
+                                           d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr, d_R.ptr))
 
 
 def tsqr_merge_base(d_Rs, count, nc, n_free, tol_qr, d_Rk):

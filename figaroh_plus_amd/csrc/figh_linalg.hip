@@ -1230,6 +1230,72 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
     return reduce_stack(stack, cnt + 1, nc, n, tol_qr, d_R_out);
 }
 
+// figh_tsqr_selected for the joint-torque regressor of a TREE of single-dof joints (regressor.py:45-87): row block j (the
+// rows of joint j) only involves the links of j's subtree (+ the Ia fv fs off columns of link j itself) -- every other
+// column is a structural zero the tape kernel writes as such.  For a chain that is the prefix structure the register-tile
+// kernel's hint exploits; for a tree (TIAGo: wheels, head, arm on one base) most of the zeros are NOT a prefix: 7 .. 85 of
+// the 240 kept columns are non-zero per row block.  Every row block is factored over its own column list (h_counts[j]
+// entries of d_cols / d_pos: device columns and positions in the kept list, concatenated; built by the caller from the
+// kept mask it expects and verified against d_sel afterwards), reduced to one triangle, embedded into the full column set,
+// and the nblocks embedded triangles are merged: 2 m sum_j n_j^2 / nblocks instead of 2 m n^2 flops (TIAGo: 2.4 %).
+int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                              int link_stride, int n_expected, int nblocks, const int32_t *h_counts, const int32_t *d_cols,
+                              const int32_t *d_pos, const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out) {
+    FIGH_REQUIRE(d_W && d_colsq && d_sel && d_R_out && h_counts && d_cols && d_pos, "NULL pointer");
+    FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
+    FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
+    FIGH_REQUIRE(n_expected >= 1 && n_expected <= ncols && n_expected < 512, "bad shape");
+    FIGH_REQUIRE(nblocks >= 1 && nblocks <= kMaxJoints && rows % nblocks == 0, "rows must be a multiple of the row blocks");
+    if (int rc = ensure_device()) return rc;
+    {
+        ProfileScope scope("select_columns");
+        hipLaunchKernelGGL(select_columns_kernel, dim3(1), dim3(256), 0, stream(), d_colsq, ncols, tol_e, link_stride, 0,
+                           (long)rows, 1L, 0L, d_sel, (int *)nullptr);
+        FIGH_HIP(hipGetLastError());
+    }
+    const int n = n_expected, nc = n + (d_tau ? 1 : 0);
+    const int64_t rows_b = rows / nblocks;
+    int nmax = 1;
+    for (int j = 0; j < nblocks; ++j) {
+        FIGH_REQUIRE(h_counts[j] >= 0 && h_counts[j] <= n, "block column count out of range");
+        nmax = std::max(nmax, h_counts[j] + (d_tau ? 1 : 0));
+    }
+    const size_t tri = sizeof(double) * (size_t)nc * nc;
+    double *stack = static_cast<double *>(workspace(tri * (size_t)(nblocks + 1), 26));
+    const int64_t cap_b = std::max(figh_tsqr_level0_capacity(nmax), figh_tsqr_level0_capacity(std::min(nmax, 80)));
+    double *tri_b = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax * cap_b, 23));
+    double *Rb = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax, 24));
+    if (!stack || !tri_b || !Rb) return FIGH_ERR_ALLOC;
+    long have = 0, off = 0;
+    for (int j = 0; j < nblocks; ++j) {
+        const int nj = h_counts[j], ncj = nj + (d_tau ? 1 : 0);
+        const double *Wj = d_W + (int64_t)j * rows_b * ldw;
+        const double *tj = d_tau ? d_tau + (int64_t)j * rows_b : nullptr;
+        if (nj == 0) {  // (only tau in this block: its norm still counts)
+            off += nj;
+            if (!d_tau) continue;
+        }
+        int64_t cnt = 0;
+        if (nj > 0) {
+            if (int rc = figh_tsqr_level0(Wj, rows_b, ldw, d_cols + off, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr))
+                return rc;
+        } else {
+            // a 1 x 1 "matrix": the tau rows alone, through the same kernel with tau as its only column
+            if (int rc = figh_tsqr_level0(tj, rows_b, 1, nullptr, 1, nullptr, nullptr, 0, tri_b, cap_b, &cnt, nullptr)) return rc;
+        }
+        if (cnt == 1) FIGH_HIP(hipMemcpyAsync(Rb, tri_b, sizeof(double) * (size_t)ncj * ncj, hipMemcpyDeviceToDevice, stream()));
+        else if (int rc = tsqr_reduce(tri_b, cnt, ncj, Rb)) return rc;
+        if (int rc = embed_force_triangle(Rb, ncj, nj, d_pos + off, nc, n, stack + (size_t)have * nc * nc)) return rc;
+        ++have;
+        off += nj;
+    }
+    if (have == 0) {
+        FIGH_HIP(hipMemsetAsync(stack, 0, tri, stream()));
+        have = 1;
+    }
+    return reduce_stack(stack, have, nc, n, tol_qr, d_R_out);
+}
+
 int figh_tsqr_merge_base(const double *d_Rs, int count, int nc, int n_free, double tol_qr, double *d_Rk_out) {
     FIGH_REQUIRE(d_Rs && d_Rk_out, "NULL device pointer");
     FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 512 && n_free >= 1 && n_free <= nc, "bad shape");

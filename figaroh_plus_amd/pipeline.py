@@ -254,6 +254,7 @@ class IdentificationPipeline:
         if self.W is None:  # HBM buffers are allocated once and reused by every step
             self._kept_cache = None
             self._n_expected = -1
+            self._mask_expected = None
             rows_per_sample, ncols = handle.shape(mode, flags)
             # W stays in HBM.  Chains: the reference's dense layout (the chain kernel streams one contiguous run per tile).
             # Trees: the link-padded layout of figh_regressor_build_padded -- 16 columns per link, every (row, link)
@@ -283,6 +284,10 @@ class IdentificationPipeline:
             self._wrench_split = (mode == _lib.MODE_EXT_WRENCH and rows_per_sample == 6 and len(m.joints) > 1 and
                                   m.joints[1].jtype == JT_FREEFLYER and not self.coupling)
             self._nf_expected = -1
+            # joint-torque regressor of a tree of single-dof joints with more than 80 kept columns (TIAGo): per row block
+            # only the columns of the joint's subtree are non-zero -- figh_tsqr_selected_blocks (lists from the kept mask)
+            self._tree_blocks = bool(structured and self._padded)
+            self._block_cache = None
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
         if self._padded:
             _lib.regressor_build_padded(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld,
@@ -298,9 +303,14 @@ class IdentificationPipeline:
             nf = self._nf_expected if split else 0
             nc = n + (1 if with_tau else 0)
             local = not getattr(ex, "collective", True)
+            blocks = self._block_lists(ncols, stride) if (getattr(self, "_tree_blocks", False) and nc > 80) else None
             if split:
                 _lib.tsqr_selected_wrench(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, nf, self.d_tau,
                                           self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
+            elif blocks is not None:
+                _lib.tsqr_selected_blocks(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, blocks[1], blocks[2],
+                                          blocks[3], self.d_tau, self.tol_qr if local else -1.0, self._d_sel,
+                                          self._d_rows if local else self._d_R)
             else:
                 _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
                                    self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
@@ -320,8 +330,10 @@ class IdentificationPipeline:
             nf_now = 0
             if split:  # kept columns that can be non-zero in force rows: slot >= 6 within the link
                 nf_now = int(np.count_nonzero(sel[2 + ncols:2 + 2 * ncols][self._force_slots(ncols)]))
-            if int(sel[0]) == n and nf_now == nf:
+            mask_now = sel[2 + ncols:2 + 2 * ncols] != 0
+            if int(sel[0]) == n and nf_now == nf and (blocks is None or np.array_equal(mask_now, blocks[0])):
                 break
+            self._mask_expected = mask_now.copy()  # (the per-block column lists are built from the mask)
             self._n_expected = int(sel[0])  # first pass, or the kept set changed size: solve again with the right shape
             self._nf_expected = nf_now
             if self._n_expected == 0:
@@ -340,6 +352,40 @@ class IdentificationPipeline:
             self._kept_cache = (kept_mask.copy(), list(idx_e), list(params_r))
         rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
         return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+
+    def _block_lists(self, ncols, stride):
+        """(mask, counts, d_cols, d_pos) for figh_tsqr_selected_blocks, from the kept mask this pass expects: row block j
+        (joint j + 1) gets the kept inertial columns of the links in that joint's subtree and the kept Ia / fv / fs / off
+        columns of its own link -- everything else in the block is a structural zero of the regressor
+        (regressor.py:45-87).  None while no mask is known."""
+        mask = getattr(self, "_mask_expected", None)
+        if mask is None or len(mask) != ncols:
+            return None
+        cached = self._block_cache
+        if cached is not None and np.array_equal(cached[0], mask):
+            return cached
+        m = self.robot.model
+        nb = m.nv
+        parents = list(m.parents)
+        anc = np.zeros((nb, nb), dtype=bool)  # anc[j, k]: joint j + 1 is joint k + 1 or one of its ancestors
+        for k in range(nb):
+            jid = k + 1
+            while jid > 0:
+                anc[jid - 1, k] = True
+                jid = parents[jid]
+        kept = np.flatnonzero(mask)
+        link, slot = kept // 14, kept % 14
+        counts, cols, pos = [], [], []
+        for j in range(nb):
+            in_block = (anc[j][np.minimum(link, nb - 1)] & (link < nb) & (slot < 10)) | ((link == j) & (slot >= 10))
+            p = np.flatnonzero(in_block)
+            counts.append(len(p))
+            pos.append(p)
+            cols.append(link[p] * stride + slot[p])
+        d_cols = _lib.DeviceArray.from_host(np.concatenate(cols + [np.zeros(1, dtype=np.int64)]).astype(np.int32))
+        d_pos = _lib.DeviceArray.from_host(np.concatenate(pos + [np.zeros(1, dtype=np.int64)]).astype(np.int32))
+        self._block_cache = (mask.copy(), np.asarray(counts, dtype=np.int32), d_cols, d_pos)
+        return self._block_cache
 
     def _force_slots(self, ncols):
         """Mask over the reference's columns: slot >= 6 within a link (mx my mz m Ia fv fs off)."""

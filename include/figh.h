@@ -212,6 +212,15 @@ int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const doubl
 int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nf_expected, const double *d_tau, double tol_qr,
                               int32_t *d_sel, double *d_R_out);
+/* figh_tsqr_selected for the joint-torque regressor of a tree of single-dof joints (regressor.py:45-87, rows j*N + i): row
+ * block j only involves the links of joint j's subtree and the Ia / fv / fs / off columns of link j itself; all other
+ * entries are structural zeros.  Row block j (rows / nblocks rows) is factored over its own column list -- h_counts[j]
+ * entries of d_cols (device column numbering) and d_pos (positions in the kept list), concatenated block after block,
+ * built by the caller from the kept mask it expects (and verified against d_sel afterwards) -- reduced, embedded into the
+ * kept column set, and the nblocks triangles are merged.  Same outputs as figh_tsqr_selected. */
+int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                              int link_stride, int n_expected, int nblocks, const int32_t *h_counts, const int32_t *d_cols,
+                              const int32_t *d_pos, const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out);
 /* figh_tsqr_merge followed by the rank decision and the regrouped factorisation as in figh_tsqr_selected (the cross-rank
  * reduction of the all-gathered per-rank triangles): columns k < n_free take part in the rank decision, the others (tau)
  * always count as base columns.  d_rows_out: (nc + 1) x nc. */

@@ -609,6 +609,52 @@ def test_wrench_force_rows_split(lib, cfg, model):
     assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * max(1.0, b_["residual_norm"])
 
 
+def test_tree_row_blocks_column_lists(lib):
+    """Joint-torque regressor of a tree (TIAGo): (i) row block j is exactly zero outside the columns the pipeline lists for
+    it (subtree of joint j + own Ia / fv / fs / off) -- the assumption figh_tsqr_selected_blocks rests on; (ii) the pass
+    that factors every row block over its own list gives the results of the plain pass."""
+    import json
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic
+    from figaroh_plus_amd.tools.robot import Robot
+    root = os.path.dirname(__file__)
+    meta = json.load(open(os.path.join(root, "golden", "cfg3_tiago.json")))
+    robot = Robot.from_flat("tiago")
+    rng = np.random.default_rng(12)
+    q, v, a = sample_inputs(robot.model, 3000, rng, 1.5, 2, 5)
+    outs = []
+    for blocks in (True, False):
+        pipe = IdentificationPipeline(robot, meta["param"], params_std=dict(zip(meta["names_std"], meta["phi_ref_raw"])))
+        pipe.set_samples(q, v, a)
+        pipe.set_tau_from_parameters(np.array([float(x) for x in meta["phi_ref_raw"]]), noise_std=0.01, seed=3)
+        out = pipe.run()
+        if blocks:
+            assert pipe._tree_blocks and pipe._block_cache is not None
+            mask, counts, d_cols, d_pos = pipe._block_cache
+            assert 0 < counts.max() < mask.sum() and counts.sum() < 0.3 * len(counts) * mask.sum()
+            # the zero pattern of W against the lists (reference layout, a slice of the samples)
+            W = build_regressor_basic(robot, q[:200], v[:200], a[:200], meta["param"])
+            kept = np.flatnonzero(mask)
+            pos = d_pos.to_host()
+            off = 0
+            for j, cnt in enumerate(counts):
+                listed = np.zeros(len(kept), dtype=bool)
+                listed[pos[off:off + cnt]] = True
+                off += cnt
+                blk = W[j * 200:(j + 1) * 200][:, kept]
+                assert not blk[:, ~listed].any(), j
+            out = pipe.run()
+        else:
+            pipe._tree_blocks = False
+            out = pipe.run()
+        outs.append(out)
+    a_, b_ = outs
+    assert a_["idx_e"] == b_["idx_e"] and a_["idx_base"] == b_["idx_base"] and a_["params_base"] == b_["params_base"]
+    assert np.abs(a_["phi_ls"] - b_["phi_ls"]).max() <= 1e-8 * max(1.0, np.abs(b_["phi_ls"]).max())
+    assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * max(1.0, b_["residual_norm"])
+
+
 def test_tx40_real_data_known_answers_hip(lib):
     """Same known-answer replay with the HIP path end to end: Butterworth filtfilt of the joint positions on the
     device, K1 on the 44 958 real samples, two decimate-by-10 stages of every column of W and of tau on the device,
