@@ -332,6 +332,19 @@ def main():
             roof["tsqr"]["pipe"] = ("fp64 matrix pipe: 16-column panels on the VALU, compact-WY trailing updates as "
                                     "v_mfma_f64_16x16x4 (figh_tsqr_wide.hip); rows whose leading columns are zero start "
                                     "at their first non-zero column, so the executed flops are below the dense 2 m n^2")
+            blocks = getattr(pipe, "_block_cache", None) if getattr(pipe, "_tree_blocks", False) else None
+            if blocks is not None:
+                # joint-torque regressor of a tree: every row block is factored over the columns of its joint's subtree only
+                # (figh_tsqr_selected_blocks).  The reference's dense count 2 m n^2 is then 40 x the flops this path is
+                # asked to execute, so `achieved` / `frac` are restated on the EXECUTED flops (they would exceed the peak
+                # otherwise) and the dense-equivalent rate is kept beside them.
+                ex = int(sum(2 * (int(c) + 1) ** 2 for c in blocks[1]))
+                roof["tsqr"]["algorithmic_equivalent_TFLOPs"] = roof["tsqr"]["achieved"]
+                roof["tsqr"]["executed_flops_per_sample"] = ex
+                roof["tsqr"]["achieved"] = ex * N / sec / 1e12
+                roof["tsqr"]["launches_per_step"] = launches_per_step["tsqr"]
+                roof["tsqr"]["pipe"] += ("; per-row-block column lists: `achieved` counts the executed flops "
+                                         "sum_j 2 (n_j + 1)^2 per sample, the launches are 24 small ones (7 .. 86 columns)")
             if getattr(pipe, "_wrench_split", False) and getattr(pipe, "_nf_expected", 0) > 0:
                 # external wrench on a free-flyer root: the three force row blocks are factored over the nf columns that
                 # can be non-zero there (figh_tsqr_selected_wrench) -- `achieved` above counts the reference's dense
