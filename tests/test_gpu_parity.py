@@ -609,6 +609,79 @@ def test_wrench_force_rows_split(lib, cfg, model):
     assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * max(1.0, b_["residual_norm"])
 
 
+@pytest.mark.parametrize("stride,with_tau,nlinks", [(16, True, 12), (14, False, 10), (16, False, 25)])
+def test_structured_tsqr_entry_points_on_synthetic_matrices(lib, stride, with_tau, nlinks):
+    """figh_tsqr_selected_wrench and figh_tsqr_selected_blocks at the C-ABI on random matrices that carry the structure
+    (no model in the loop): R^T R of the plain triangle they return equals W_kept^T W_kept; with and without tau, both
+    link strides, a block without any column, the fall-backs (too few rows / nf == n)."""
+    rng = np.random.default_rng(stride * 100 + nlinks)
+    ncols = 14 * nlinks
+    ld = stride * nlinks
+    # ---- six wrench row blocks: rotational-inertia columns zero in the force blocks; some all-zero (eliminated) columns
+    Nb = 900
+    rows = 6 * Nb
+    Wref = rng.standard_normal((rows, ncols))
+    dead = rng.choice(ncols, ncols // 5, replace=False)
+    Wref[:, dead] = 0.0
+    Wref[:3 * Nb][:, (np.arange(ncols) % 14) < 6] = 0.0
+    tau = rng.standard_normal(rows)
+
+    def to_device_layout(Wr):
+        Wd = np.zeros((Wr.shape[0], ld))
+        c = np.arange(ncols)
+        Wd[:, (c // 14) * stride + c % 14] = Wr
+        return Wd
+
+    def run(entry, Wr, extra):
+        Wd = to_device_layout(Wr)
+        d_W = lib.DeviceArray.from_host(Wd.reshape(-1))
+        d_cs = lib.DeviceArray.from_host((Wr ** 2).sum(axis=0))
+        d_tau = lib.DeviceArray.from_host(tau[:Wr.shape[0]]) if with_tau else None
+        d_sel = lib.DeviceArray((2 + 2 * ncols,), np.int32)
+        kept = np.flatnonzero((Wr ** 2).sum(axis=0) >= 1e-6)
+        n = len(kept)
+        nc = n + (1 if with_tau else 0)
+        d_R = lib.DeviceArray((nc * nc,))
+        entry(d_W, Wr.shape[0], ld, d_cs, ncols, 1e-6, stride, n, *extra(kept), d_tau, -1.0, d_sel, d_R)
+        sel = d_sel.to_host()
+        assert sel[0] == n and np.array_equal(sel[2:2 + n], (kept // 14) * stride + kept % 14)
+        R = d_R.to_host().reshape(nc, nc)
+        A = Wr[:, kept] if not with_tau else np.c_[Wr[:, kept], tau[:Wr.shape[0]]]
+        G = A.T @ A
+        assert np.array_equal(R, np.triu(R))
+        assert np.abs(R.T @ R - G).max() <= 1e-11 * np.abs(G).max()
+        return kept
+
+    if 14 * nlinks // 2 > 80:  # (the split needs the blocked kernel: more than 80 kept columns)
+        run(lib.tsqr_selected_wrench, Wref, lambda kept: (int(np.count_nonzero(kept % 14 >= 6)),))
+        run(lib.tsqr_selected_wrench, Wref, lambda kept: (0,))                      # nf unknown: plain path
+        run(lib.tsqr_selected_wrench, Wref[:6 * 40], lambda kept: (int(np.count_nonzero(kept % 14 >= 6)),))  # too few rows
+    # ---- nb row blocks with their own column subsets (one of them empty)
+    nb = 7
+    Nb2 = 700
+    Wb = np.zeros((nb * Nb2, ncols))
+    live = np.setdiff1d(np.arange(ncols), dead)
+    subsets = []
+    for j in range(nb):
+        k = 0 if j == 3 else int(rng.integers(3, min(100, len(live))))
+        sub = np.sort(rng.choice(live, k, replace=False))
+        subsets.append(sub)
+        Wb[j * Nb2:(j + 1) * Nb2][:, sub] = rng.standard_normal((Nb2, k))
+
+    def block_args(kept):
+        where = {c: i for i, c in enumerate(kept.tolist())}
+        subs = [np.array([c for c in sub.tolist() if c in where], dtype=np.int64) for sub in subsets]
+        counts = np.array([len(x) for x in subs], dtype=np.int32)
+        cols = np.concatenate(subs + [np.zeros(1, dtype=np.int64)])
+        pos = np.array([where[c] for x in subs for c in x.tolist()] + [0], dtype=np.int32)
+        d_cols = lib.DeviceArray.from_host(((cols // 14) * stride + cols % 14).astype(np.int32))
+        d_pos = lib.DeviceArray.from_host(pos)
+        block_args.keep = (d_cols, d_pos)
+        return counts, d_cols, d_pos
+
+    run(lib.tsqr_selected_blocks, Wb, block_args)
+
+
 def test_tree_row_blocks_column_lists(lib):
     """Joint-torque regressor of a tree (TIAGo): (i) row block j is exactly zero outside the columns the pipeline lists for
     it (subtree of joint j + own Ia / fv / fs / off) -- the assumption figh_tsqr_selected_blocks rests on; (ii) the pass
