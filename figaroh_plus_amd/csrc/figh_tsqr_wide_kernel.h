@@ -816,6 +816,10 @@ struct WyConfig {
     // the tallest tile the 256 registers of a wave hold: the rows one look-ahead chain covers are what the throughput is
     // proportional to (same-box A/B, n = 191: 64 -> 80 -> 96 rows +11 %, +5.5 %; n = 241: 64 -> 80 rows +6 %; the last
     // step of each costs 8 / 22 spilled registers and still wins)
+    // up to six chunks (81 .. 96 columns: the widest row blocks of a tree's joint-torque regressor): two waves per
+    // workgroup -- the tile time is the look-ahead chain whatever the wave count, so more, smaller workgroups per CU
+    // (three by LDS instead of two) carry more chains at a time
+    if (nch <= 6) return {2, 3, 6, 2, 0};
     if (nch <= 12) return {4, 3, 6, 2, 0};
     if (nch <= 16) return {4, 4, 5, 2, 0};
     if (nch <= 20) return {4, 5, 4, 2, 0};
@@ -836,6 +840,7 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
         return true;                                                                               \
     }
 #define FIGH_WY_CASE(NW_, CPW_, NRC_, WPE_) FIGH_WY_CASE_L(NW_, CPW_, NRC_, WPE_, false)
+    FIGH_WY_CASE(2, 3, 6, 2)
     FIGH_WY_CASE(4, 3, 6, 2)
     FIGH_WY_CASE(4, 4, 5, 2)
     FIGH_WY_CASE(4, 5, 4, 2)

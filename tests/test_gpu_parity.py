@@ -771,7 +771,7 @@ def test_tx40_real_data_known_answers_hip(lib):
     assert (np.abs(std_w - z["std_wls"])[ok] / z["std_wls"][ok]).max() <= 2e-3
 
 
-@pytest.mark.parametrize("n", [1, 15, 16, 17, 49, 63, 64, 65, 79, 80, 81, 128, 193, 200, 257, 272, 305, 320, 330, 336, 384, 400,
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 49, 63, 64, 65, 79, 80, 81, 95, 96, 97, 128, 193, 200, 257, 272, 305, 320, 330, 336, 384, 400,
                                511])
 @pytest.mark.parametrize("rows", [1, 63, 64, 65, 1000, 20011])
 def test_tsqr_shapes_against_lapack(lib, n, rows):
@@ -1461,7 +1461,7 @@ def test_handwritten_robot_against_first_principles(lib, tmp_path, freeflyer):
     assert np.abs(Wrec - W0[:, inertial]).max() <= 1e-5 * np.abs(W0).max()
 
 
-@pytest.mark.parametrize("n", [50, 70, 81, 191, 241, 305, 331, 400, 511])
+@pytest.mark.parametrize("n", [50, 70, 81, 96, 191, 241, 305, 331, 400, 511])
 def test_tsqr_ragged_rows_inside_a_nan_filled_buffer(lib, n):
     """the blocked kernel zero-fills the rows of a ragged last tile through the range check of its buffer
     descriptor (and the register-tile kernel clamps and masks them).  W is therefore placed as the first `rows` rows of a
