@@ -66,6 +66,7 @@ namespace {
 
 #ifdef FIGH_ABLATION
 __device__ int g_tree_hotin = 0;
+__device__ int g_tree_half = 0;  // FIGH_TREE_HALF: force rows store only the upper 64 bytes of every line (timing probe)
 #endif
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -77,7 +78,7 @@ template <int LS, bool STORE, bool COLSQ>
 __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, double *__restrict__ red,
                                            double *__restrict__ colacc, const int lane, const int nvalid,
                                            double *__restrict__ W, const long ldw, const unsigned ldw8, const long rowbase,
-                                           const int col0) {
+                                           const int col0, const bool skip_lo = false) {
     constexpr int CP = LS / 2, RPI = 64 / CP;  // 16-byte chunks per row, rows per store instruction
     const int rg = lane / CP, ch = lane - rg * CP;
     const bool active = rg < RPI;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
                     acc0 = fma(x.x, x.x, acc0);
                     acc1 = fma(x.y, x.y, acc1);
                 }
-                if constexpr (STORE) {
+                if (STORE && !(skip_lo && ch < CP / 2)) {
                     u32x4 d;
                     d[0] = (unsigned)__double2loint(x.x);
                     d[1] = (unsigned)__double2hiint(x.x);
@@ -397,7 +398,12 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const long rowbase = (long)(EXTFF ? c : ob) * N + i0;
                     if constexpr (VEC2) {
+#ifdef FIGH_ABLATION
+                        flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0,
+                                                     EXTFF && g_tree_half && c < 3);
+#else
                         flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0);
+#endif
                     } else {  // odd column count / unaligned W: plain 8-byte stores, no fused norms
                         for (int id = lane; id < nvalid * 14; id += 64) {
                             const int row = id / 14, col = id - 14 * row;
@@ -648,6 +654,8 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
         {
             const int hot = getenv("FIGH_TREE_HOTIN") != nullptr;
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tree_hotin), &hot, sizeof(int));
+            const int half = getenv("FIGH_TREE_HALF") != nullptr;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tree_half), &half, sizeof(int));
         }
         if (const char *e = getenv("FIGH_TREE_TAPE")) {  // store-pattern ceilings: W is all zeros, timing only
             TapeBuilder T(h);
