@@ -174,6 +174,11 @@ def main():
     ap.add_argument("--placement-trials", type=int, default=8,
                     help="set-up (untimed): candidate allocations of W among which the one K1 writes fastest is kept "
                          "(IdentificationPipeline.placement_trials; 1 = take the first)")
+    ap.add_argument("--structural-zeros", default="every-pass", choices=["every-pass", "once"],
+                    help="once = opt-in variant for the joint-torque regressor of a tree (cfg3): W is zero-filled at set-up "
+                         "and the regressor kernel leaves its structural zeros alone (FIGH_FLAG_ZEROS_PRESENT); every entry "
+                         "that depends on the inputs is still written in every pass.  Reported in config.structural_zeros; "
+                         "the default re-creates every byte of W in every pass")
     ap.add_argument("--host-wait", default=None, choices=["spin", "block"],
                     help="how the host waits for the GPU: spin (default for one GPU) or block = interrupt-driven (default "
                          "for several ranks on a node: spinning ranks can exhaust a container's CPU quota)")
@@ -231,7 +236,8 @@ def main():
     else:
         q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
     pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
-                                  chunk_samples=chunk, placement_trials=args.placement_trials)
+                                  chunk_samples=chunk, placement_trials=args.placement_trials,
+                                  structural_zeros=args.structural_zeros)
     _lib.synchronize()
     t_h2d = time.perf_counter()
     pipe.set_samples(q, v, a)
@@ -425,6 +431,7 @@ def main():
                 "device": _lib.device_info()["name"], "result_matches_reference": bool(ok),
                 "figh_env": "none set (checked)", "host_wait": host_wait,
                 "w_placement": pipe.placement_report or {"trials": 1},
+                "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
             "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},

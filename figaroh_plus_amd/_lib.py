@@ -20,6 +20,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -
 
 MODE_JOINT_TORQUE, MODE_EXT_WRENCH = 0, 1
 FLAG_FRICTION, FLAG_ACT_INERTIA, FLAG_OFFSET, FLAG_TX40, FLAG_GENERIC, FLAG_BLOCKED_INPUTS = 1, 2, 4, 8, 256, 512
+FLAG_ZEROS_PRESENT = 1024  # opt-in of figh_regressor_build_padded: structural zeros of W are already there (figh.h)
 
 _c_double_p = C.POINTER(C.c_double)
 _c_int32_p = C.POINTER(C.c_int32)

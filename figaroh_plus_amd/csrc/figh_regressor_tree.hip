@@ -585,7 +585,7 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
         int prev = -1, zero_from = -1;
         auto flush_zero = [&](int upto_link) {
             if (zero_from < 0) return;
-            T.zero(row, ls * (zero_from - 1), ls * (upto_link - zero_from));
+            if (!(flags & FIGH_FLAG_ZEROS_PRESENT)) T.zero(row, ls * (zero_from - 1), ls * (upto_link - zero_from));
             zero_from = -1;
         };
         for (int b = 1; b <= nl; ++b) {
@@ -646,7 +646,8 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     for (int k = extff ? 2 : 1; k < h.njoints; ++k)
         FIGH_REQUIRE(h.jtype[k] != FIGH_JT_FREEFLYER, "a free-flyer joint is only supported as the root joint of the "
                                                       "external-wrench mode");
-    const std::vector<long> key = {(long)reinterpret_cast<uintptr_t>(m), mode, flags & (7 | FIGH_FLAG_TX40), ft_mask, ls};
+    const std::vector<long> key = {(long)reinterpret_cast<uintptr_t>(m), mode,
+                                   flags & (7 | FIGH_FLAG_TX40 | FIGH_FLAG_ZEROS_PRESENT), ft_mask, ls};
     auto it = g_tapes.find(key);
     if (it == g_tapes.end()) {
         std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls) : build_tape_rows(h, mode, flags, ft_mask, ls);

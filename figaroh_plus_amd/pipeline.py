@@ -70,12 +70,19 @@ def _solve_upper(R1, B):
 
 class IdentificationPipeline:
     def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
-                 chunk_samples=None, placement_trials=1):
+                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass"):
         """``chunk_samples``: when the stacked regressor of all N samples does not fit HBM (human model at 1e7
         samples: 269 GB) the samples are processed in chunks of this size -- pass 1 accumulates diag(W^T W), pass 2
         rebuilds each chunk's W (recomputing is far cheaper than storing), factors it and stacks the triangles,
         which ``figh_tsqr_merge`` reduces.  Results are those of the one-shot pass (R is row-order independent)."""
         self.chunk_samples = chunk_samples
+        # structural_zeros = "once" (opt-in, joint-torque regressor of a tree kept in HBM): W is zero-filled when it is
+        # allocated and the regressor kernel is told that the structural zeros are present (FIGH_FLAG_ZEROS_PRESENT) -- it
+        # rewrites every entry that depends on q, v, a in every pass and leaves the zeros alone.  The default re-creates
+        # every byte of W in every pass.
+        if structural_zeros not in ("every-pass", "once"):
+            raise ValueError("structural_zeros must be 'every-pass' or 'once'")
+        self.structural_zeros = structural_zeros
         # placement_trials > 1: when W is allocated, that many candidate buffers are allocated side by side, the regressor
         # kernel is timed on each and the fastest one is kept (set-up cost: a few passes of K1).  The time K1 needs for the
         # same 4 GB depends on the physical pages behind them -- 0.68 or 0.82 ms per allocation, hipMemset moves with it
@@ -263,6 +270,9 @@ class IdentificationPipeline:
             wcols = 16 * (self.robot.model.njoints - 1) if self._padded else ncols
             self.W = self._place_W(rows_per_sample * self.N, wcols, handle, mode, flags, ft_mask)
             self.W.ref_cols = ncols
+            self._zeros_once = (self.structural_zeros == "once" and self._padded and mode == _lib.MODE_JOINT_TORQUE)
+            if self._zeros_once:
+                _lib.check(_lib.load().figh_memset(self.W.buf.ptr, 0, self.W.rows * self.W.ld * 8))
             cap = ncols + 1
             # one buffer for everything that returns to the host: [colsq (ncols f64) | sel (2 + 2 ncols i32) | rows ((cap+1) cap f64)]
             self._sel_words = (2 + 2 * ncols + 1) // 2
@@ -290,8 +300,8 @@ class IdentificationPipeline:
             self._block_cache = None
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
         if self._padded:
-            _lib.regressor_build_padded(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld,
-                                        d_colsq)
+            _lib.regressor_build_padded(handle, mode, flags | (_lib.FLAG_ZEROS_PRESENT if self._zeros_once else 0), ft_mask,
+                                        self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         else:
             _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         ex.sum_columns_device(d_colsq, W.ref_cols)

@@ -47,7 +47,14 @@ enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, 
         * the reference's sample-major arrays: the generic-tree kernel then reads one 512-byte line per value and wave
         * (sample-major, a lane's values lie nq * 8 bytes from its neighbour's and every 8-byte load pulls a line of its
         * own: 7.4x the algorithmic input bytes on TALOS).  Tree models only. */
-       FIGH_FLAG_BLOCKED_INPUTS = 512 };
+       FIGH_FLAG_BLOCKED_INPUTS = 512,
+       /* figh_regressor_build_padded only, OPT-IN: the caller guarantees that the structural zeros of W (the entries of a
+        * row block outside its joint's subtree, joint-torque mode of a tree) already ARE zero in d_W -- a buffer it
+        * zero-filled once and that nothing but this function writes -- so the kernel does not stream them again; every
+        * entry that depends on q, v, a is written as always.  90 % of TIAGo's 73.7 GB are such zeros.  Not the default
+        * of anything: a pass that re-creates every byte of W each time is what the pipeline and bench.py measure unless
+        * asked otherwise. */
+       FIGH_FLAG_ZEROS_PRESENT = 1024 };
 
 typedef struct figh_model_s *figh_model_t;
 

@@ -728,6 +728,37 @@ def test_tree_row_blocks_column_lists(lib):
     assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * max(1.0, b_["residual_norm"])
 
 
+def test_structural_zeros_once_keeps_W_exact(lib):
+    """Opt-in FIGH_FLAG_ZEROS_PRESENT (IdentificationPipeline(structural_zeros="once")): W is zero-filled once, the kernel
+    rewrites the data-dependent entries only -- after repeated passes W equals the regressor the default kernel writes,
+    bit for bit, and the results are those of the default pipeline."""
+    import json
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
+    from figaroh_plus_amd.tools.robot import Robot
+    root = os.path.dirname(__file__)
+    meta = json.load(open(os.path.join(root, "golden", "cfg3_tiago.json")))
+    robot = Robot.from_flat("tiago")
+    rng = np.random.default_rng(13)
+    sets = [sample_inputs(robot.model, 1500, rng, 1.5, 2, 5) for _ in range(2)]
+    phi = np.array([float(x) for x in meta["phi_ref_raw"]])
+    res = {}
+    for mode in ("once", "every-pass"):
+        pipe = IdentificationPipeline(robot, meta["param"], params_std=dict(zip(meta["names_std"], meta["phi_ref_raw"])),
+                                      structural_zeros=mode)
+        for q, v, a in sets:  # (set_samples allocates a fresh W: zero-filled again in "once" mode)
+            pipe.set_samples(q, v, a)
+            pipe.set_tau_from_parameters(phi, noise_std=0.01, seed=5)
+            out = pipe.run()
+            out = pipe.run()  # second pass into the same buffer
+        assert getattr(pipe, "_zeros_once", False) == (mode == "once")
+        res[mode] = (out, pipe.W.numpy().copy())
+    assert np.array_equal(res["once"][1], res["every-pass"][1])
+    a_, b_ = res["once"][0], res["every-pass"][0]
+    assert a_["idx_e"] == b_["idx_e"] and a_["idx_base"] == b_["idx_base"] and a_["params_base"] == b_["params_base"]
+    assert np.array_equal(a_["phi_ls"], b_["phi_ls"])
+
+
 def test_tx40_real_data_known_answers_hip(lib):
     """Same known-answer replay with the HIP path end to end: Butterworth filtfilt of the joint positions on the
     device, K1 on the 44 958 real samples, two decimate-by-10 stages of every column of W and of tau on the device,
