@@ -179,6 +179,11 @@ def main():
                          "and the regressor kernel leaves its structural zeros alone (FIGH_FLAG_ZEROS_PRESENT); every entry "
                          "that depends on the inputs is still written in every pass.  Reported in config.structural_zeros; "
                          "the default re-creates every byte of W in every pass")
+    ap.add_argument("--w-layout", default="auto", choices=["auto", "dense", "block-compact"],
+                    help="how W is kept in HBM.  dense = the reference's rows (link-padded for trees).  block-compact (trees "
+                         "in joint-torque mode, cfg3) = row block j as its own N x 16 |subtree_j| matrix: only the window of a "
+                         "row that can be non-zero is stored, written and read, every stored byte in every pass "
+                         "(FIGH_FLAG_COMPACT_BLOCKS).  auto = block-compact where it applies; config.w_layout says which")
     ap.add_argument("--host-wait", default=None, choices=["spin", "block"],
                     help="how the host waits for the GPU: spin (default for one GPU) or block = interrupt-driven (default "
                          "for several ranks on a node: spinning ranks can exhaust a container's CPU quota)")
@@ -237,7 +242,8 @@ def main():
         q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
     pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
                                   chunk_samples=chunk, placement_trials=args.placement_trials,
-                                  structural_zeros=args.structural_zeros)
+                                  structural_zeros=args.structural_zeros,
+                                  w_layout="dense" if args.w_layout == "dense" else "block-compact")
     _lib.synchronize()
     t_h2d = time.perf_counter()
     pipe.set_samples(q, v, a)
@@ -301,7 +307,7 @@ def main():
                  # tree models: q, v, a re-laid per 64-sample tile once after the upload (figh_repack_samples), part of
                  # "device-resident q, v, a -> result" but not of the repeated pass (the copies stay resident)
                  "repack_inputs_ms": getattr(pipe, "repack_ms", 0.0)}
-    if rank == 0 and pipe.W is not None and pipe.W.rows * pipe.W.ld * 8 <= 8e9:
+    if rank == 0 and pipe.W is not None and getattr(pipe, "_compact", None) is None and pipe.W.rows * pipe.W.ld * 8 <= 8e9:
         # what the drop-in boundary pays when W itself is handed back to a NumPy caller (never part of `value`)
         host_W = np.empty(pipe.W.rows * pipe.W.ld)
         _lib.synchronize()
@@ -431,6 +437,9 @@ def main():
                 "device": _lib.device_info()["name"], "result_matches_reference": bool(ok),
                 "figh_env": "none set (checked)", "host_wait": host_wait,
                 "w_placement": pipe.placement_report or {"trials": 1},
+                "w_layout": ("block-compact: row block j = N x 16 |subtree_j| (%.1f GB instead of %.1f GB)"
+                             % (8e-9 * pipe.N * float(pipe._compact[1].sum()), 8e-9 * pipe.W.rows * pipe.W.ld))
+                if getattr(pipe, "_compact", None) is not None else "dense",
                 "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,

@@ -20,6 +20,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -
 
 MODE_JOINT_TORQUE, MODE_EXT_WRENCH = 0, 1
 FLAG_FRICTION, FLAG_ACT_INERTIA, FLAG_OFFSET, FLAG_TX40, FLAG_GENERIC, FLAG_BLOCKED_INPUTS = 1, 2, 4, 8, 256, 512
+FLAG_COMPACT_BLOCKS = 2048  # figh_regressor_build_padded writes the block-compact W (figh.h)
 FLAG_ZEROS_PRESENT = 1024  # opt-in of figh_regressor_build_padded: structural zeros of W are already there (figh.h)
 
 _c_double_p = C.POINTER(C.c_double)
@@ -70,8 +71,8 @@ SIGNATURES = {
     "figh_tsqr_selected_wrench": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected_blocks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
-                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
-                                            C.c_void_p, C.c_void_p]),
+                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_merge_base": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
@@ -423,12 +424,19 @@ def tsqr_selected_wrench(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_e
 
 
 def tsqr_selected_blocks(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_expected, counts, d_cols, d_pos, d_tau,
-                         tol_qr, d_sel, d_R):
+                         tol_qr, d_sel, d_R, block_off=None, block_ld=None):
     """tsqr_selected with one column list per row block (joint-torque regressor of a tree, figh.h); ``counts``: int32
-    host array, one entry per row block."""
+    host array, one entry per row block; ``block_off`` / ``block_ld``: the block-compact W (element offsets, int64, and
+    leading dimensions, int32, per row block)."""
     counts = np.ascontiguousarray(counts, dtype=np.int32)
+    off = ld = None
+    if block_off is not None:
+        off = np.ascontiguousarray(block_off, dtype=np.int64)
+        ld = np.ascontiguousarray(block_ld, dtype=np.int32)
     check(load().figh_tsqr_selected_blocks(d_W.ptr, rows, ldw, d_colsq.ptr, ncols, tol_e, link_stride, n_expected,
                                            len(counts), counts.ctypes.data, d_cols.ptr, d_pos.ptr,
+                                           off.ctypes.data if off is not None else None,
+                                           ld.ctypes.data if ld is not None else None,
                                            d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr, d_R.ptr))
 
 

@@ -1240,8 +1240,10 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
 // and the nblocks embedded triangles are merged: 2 m sum_j n_j^2 / nblocks instead of 2 m n^2 flops (TIAGo: 2.4 %).
 int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nblocks, const int32_t *h_counts, const int32_t *d_cols,
-                              const int32_t *d_pos, const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out) {
+                              const int32_t *d_pos, const int64_t *h_block_off, const int32_t *h_block_ld,
+                              const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out) {
     FIGH_REQUIRE(d_W && d_colsq && d_sel && d_R_out && h_counts && d_cols && d_pos, "NULL pointer");
+    FIGH_REQUIRE((h_block_off == nullptr) == (h_block_ld == nullptr), "block offsets and leading dimensions come together");
     FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
     FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
     FIGH_REQUIRE(n_expected >= 1 && n_expected <= ncols && n_expected < 512, "bad shape");
@@ -1269,7 +1271,9 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     long have = 0, off = 0;
     for (int j = 0; j < nblocks; ++j) {
         const int nj = h_counts[j], ncj = nj + (d_tau ? 1 : 0);
-        const double *Wj = d_W + (int64_t)j * rows_b * ldw;
+        // (block-compact W, FIGH_FLAG_COMPACT_BLOCKS: every row block is a matrix of its own; d_cols are then columns of it)
+        const double *Wj = h_block_off ? d_W + h_block_off[j] : d_W + (int64_t)j * rows_b * ldw;
+        const int64_t ldj = h_block_ld ? h_block_ld[j] : ldw;
         const double *tj = d_tau ? d_tau + (int64_t)j * rows_b : nullptr;
         if (nj == 0) {  // (only tau in this block: its norm still counts)
             off += nj;
@@ -1277,7 +1281,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         }
         int64_t cnt = 0;
         if (nj > 0) {
-            if (int rc = figh_tsqr_level0(Wj, rows_b, ldw, d_cols + off, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr))
+            if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr))
                 return rc;
         } else {
             // a 1 x 1 "matrix": the tau rows alone, through the same kernel with tau as its only column

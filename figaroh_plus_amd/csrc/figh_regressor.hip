@@ -562,7 +562,8 @@ extern "C" int figh_regressor_build_padded(figh_model_t model, int mode, int fla
         return FIGH_OK;
     }
     int done = 0;
-    return launch_regressor_tree(model, mode, flags & (7 | FIGH_FLAG_BLOCKED_INPUTS | FIGH_FLAG_ZEROS_PRESENT), ft_mask, N,
+    return launch_regressor_tree(model, mode, flags & (7 | FIGH_FLAG_BLOCKED_INPUTS | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS),
+                                 ft_mask, N,
                                  d_q, d_v, d_a, d_W, ldw,
                                  ncols, 16, d_colsq, &done);
 }

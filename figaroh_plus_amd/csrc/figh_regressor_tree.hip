@@ -78,7 +78,7 @@ template <int LS, bool STORE, bool COLSQ>
 __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, double *__restrict__ red,
                                            double *__restrict__ colacc, const int lane, const int nvalid,
                                            double *__restrict__ W, const long ldw, const unsigned ldw8, const long rowbase,
-                                           const int col0, const bool skip_lo = false) {
+                                           const int col0, const bool skip_lo = false, const int col0_acc = -1) {
     constexpr int CP = LS / 2, RPI = 64 / CP;  // 16-byte chunks per row, rows per store instruction
     const int rg = lane / CP, ch = lane - rg * CP;
     const bool active = rg < RPI;
@@ -120,8 +120,9 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
                 s0 += red[2 * (CP * r + lane)];
                 s1 += red[2 * (CP * r + lane) + 1];
             }
-            colacc[col0 + 2 * lane] += s0;
-            colacc[col0 + 2 * lane + 1] += s1;
+            const int ca = col0_acc >= 0 ? col0_acc : col0;  // (block-compact W: the norms keep the dense numbering)
+            colacc[ca + 2 * lane] += s0;
+            colacc[ca + 2 * lane + 1] += s1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -398,12 +399,21 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const long rowbase = (long)(EXTFF ? c : ob) * N + i0;
                     if constexpr (VEC2) {
+                        if (!EXTFF && od != 0) {
+                            // FIGH_FLAG_COMPACT_BLOCKS: row block ob is its own N x ld matrix -- the columns of its joint's
+                            // subtree, a contiguous window of the dense row -- at W + N * (ld's prefix sum); od = the
+                            // segment's column in it | ld << 16, oe = the prefix sum
+                            const long ldc = od >> 16;
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W + (long)N * oe, ldc,
+                                                         8u * (unsigned)ldc, i0, (od & 0xffff) - 1, false, col0);
+                        } else {
 #ifdef FIGH_ABLATION
-                        flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0,
-                                                     EXTFF && g_tree_half && c < 3);
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0,
+                                                         EXTFF && g_tree_half && c < 3);
 #else
-                        flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0);
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0);
 #endif
+                        }
                     } else {  // odd column count / unaligned W: plain 8-byte stores, no fused norms
                         for (int id = lane; id < nvalid * 14; id += 64) {
                             const int row = id / 14, col = id - 14 * row;
@@ -576,6 +586,7 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
     const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
     const int nrows = ext ? 6 : h.nv;
     const int nl = h.nlinks;
+    int compact_prefix = 0;  // block-compact W: sum of the leading dimensions of the row blocks in front
     for (int row = 0; row < nrows; ++row) {
         int j = 0;  // the joint that owns dof `row`
         for (int k = 1; k < h.njoints; ++k)
@@ -583,11 +594,14 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
         const bool row_inert = j > 0 && (!ext || ((ft_mask >> row) & 1));
         const int s0 = j > 0 ? j : nl + 1, s1 = j > 0 ? T.subtree_end(j) : nl + 1;  // links s0 .. s1-1 = subtree
         int prev = -1, zero_from = -1;
+        const bool compact = (flags & FIGH_FLAG_COMPACT_BLOCKS) != 0;
         auto flush_zero = [&](int upto_link) {
             if (zero_from < 0) return;
-            if (!(flags & FIGH_FLAG_ZEROS_PRESENT)) T.zero(row, ls * (zero_from - 1), ls * (upto_link - zero_from));
+            if (!(flags & (FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS)))
+                T.zero(row, ls * (zero_from - 1), ls * (upto_link - zero_from));
             zero_from = -1;
         };
+        const int ld_row = ls * (s1 - s0);  // block-compact: the row block's own leading dimension (its subtree's links)
         for (int b = 1; b <= nl; ++b) {
             const bool in_sub = b >= s0 && b < s1;
             const bool inert = row_inert && in_sub && (!ext || h.body_mask[b]);
@@ -603,12 +617,14 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
             if (inert || extra) {
                 flush_zero(b);
                 T.push(OP_EMIT, b, row,
-                       (inert ? EMIT_INERT : 0) | (extra ? EMIT_EXTRA : 0) | ((!ext && b == j && row_inert) ? EMIT_OWN : 0));
+                       (inert ? EMIT_INERT : 0) | (extra ? EMIT_EXTRA : 0) | ((!ext && b == j && row_inert) ? EMIT_OWN : 0),
+                       compact ? ((ls * (b - s0) + 1) | (ld_row << 16)) : 0, compact ? compact_prefix : 0);
             } else if (zero_from < 0) {
                 zero_from = b;
             }
         }
         flush_zero(nl + 1);
+        compact_prefix += ld_row;
     }
     if (flags & FIGH_FLAG_TX40) T.push(OP_TX40, ls * nl);
     return with_fetches(h, T.ops);
@@ -646,8 +662,14 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     for (int k = extff ? 2 : 1; k < h.njoints; ++k)
         FIGH_REQUIRE(h.jtype[k] != FIGH_JT_FREEFLYER, "a free-flyer joint is only supported as the root joint of the "
                                                       "external-wrench mode");
+    if (flags & FIGH_FLAG_COMPACT_BLOCKS) {
+        FIGH_REQUIRE(mode == FIGH_MODE_JOINT_TORQUE && ls == 16 && h.nv == h.njoints - 1 && !(flags & FIGH_FLAG_TX40),
+                     "block-compact W: joint-torque regressor of single-dof joints, link-padded columns");
+        FIGH_REQUIRE(16L * h.nlinks < (1L << 15), "block-compact W: too many links");
+    }
     const std::vector<long> key = {(long)reinterpret_cast<uintptr_t>(m), mode,
-                                   flags & (7 | FIGH_FLAG_TX40 | FIGH_FLAG_ZEROS_PRESENT), ft_mask, ls};
+                                   flags & (7 | FIGH_FLAG_TX40 | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS), ft_mask,
+                                   ls};
     auto it = g_tapes.find(key);
     if (it == g_tapes.end()) {
         std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls) : build_tape_rows(h, mode, flags, ft_mask, ls);

@@ -70,7 +70,7 @@ def _solve_upper(R1, B):
 
 class IdentificationPipeline:
     def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
-                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass"):
+                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass", w_layout="dense"):
         """``chunk_samples``: when the stacked regressor of all N samples does not fit HBM (human model at 1e7
         samples: 269 GB) the samples are processed in chunks of this size -- pass 1 accumulates diag(W^T W), pass 2
         rebuilds each chunk's W (recomputing is far cheaper than storing), factors it and stacks the triangles,
@@ -83,6 +83,14 @@ class IdentificationPipeline:
         if structural_zeros not in ("every-pass", "once"):
             raise ValueError("structural_zeros must be 'every-pass' or 'once'")
         self.structural_zeros = structural_zeros
+        # w_layout = "block-compact" (joint-torque regressor of a tree kept in HBM, FIGH_FLAG_COMPACT_BLOCKS): W is stored row
+        # block by row block, block j as its own N x 16 |subtree_j| matrix -- the window of the row that can be non-zero.
+        # Nothing else is written or read (the TSQR takes one column list per row block anyway); every stored byte is written
+        # in every pass.  self.W is then that buffer (rows = nv N, `compact` = (offsets, leading dimensions)), not the
+        # reference's matrix: build_regressor_basic still returns that.
+        if w_layout not in ("dense", "block-compact"):
+            raise ValueError("w_layout must be 'dense' or 'block-compact'")
+        self.w_layout = w_layout
         # placement_trials > 1: when W is allocated, that many candidate buffers are allocated side by side, the regressor
         # kernel is timed on each and the fastest one is kept (set-up cost: a few passes of K1).  The time K1 needs for the
         # same 4 GB depends on the physical pages behind them -- 0.68 or 0.82 ms per allocation, hipMemset moves with it
@@ -268,9 +276,28 @@ class IdentificationPipeline:
             # segment one 128-byte line -- which K1' writes at about twice the rate; the TSQR takes a column list anyway.
             self._padded = not (handle.is_chain() and mode == _lib.MODE_JOINT_TORQUE) and not self.coupling
             wcols = 16 * (self.robot.model.njoints - 1) if self._padded else ncols
-            self.W = self._place_W(rows_per_sample * self.N, wcols, handle, mode, flags, ft_mask)
+            m = self.robot.model
+            self._compact = None
+            if (self.w_layout == "block-compact" and self._padded and mode == _lib.MODE_JOINT_TORQUE
+                    and m.nv == m.njoints - 1 and self.N >= 64):
+                sizes = self._subtree_sizes()
+                for k in range(m.nv):  # depth-first numbering: the subtree of joint j + 1 is the links j .. j + size - 1
+                    jid = k + 1
+                    while jid > 0:
+                        if not (jid - 1 <= k < jid - 1 + sizes[jid - 1]):
+                            raise RuntimeError("block-compact W needs depth-first joint numbering")
+                        jid = m.parents[jid]
+                ld = 16 * sizes
+                off = self.N * np.concatenate([[0], np.cumsum(ld)[:-1]])
+                self._compact = (off.astype(np.int64), ld.astype(np.int32))
+                self.W = GpuMatrix(_lib.DeviceArray((int(self.N * ld.sum()),), np.float64), rows_per_sample * self.N, wcols,
+                                   wcols)
+                self.W.compact = self._compact
+            else:
+                self.W = self._place_W(rows_per_sample * self.N, wcols, handle, mode, flags, ft_mask)
             self.W.ref_cols = ncols
-            self._zeros_once = (self.structural_zeros == "once" and self._padded and mode == _lib.MODE_JOINT_TORQUE)
+            self._zeros_once = (self.structural_zeros == "once" and self._padded and mode == _lib.MODE_JOINT_TORQUE
+                                and self._compact is None)
             if self._zeros_once:
                 _lib.check(_lib.load().figh_memset(self.W.buf.ptr, 0, self.W.rows * self.W.ld * 8))
             cap = ncols + 1
@@ -297,10 +324,13 @@ class IdentificationPipeline:
             # joint-torque regressor of a tree of single-dof joints with more than 80 kept columns (TIAGo): per row block
             # only the columns of the joint's subtree are non-zero -- figh_tsqr_selected_blocks (lists from the kept mask)
             self._tree_blocks = bool(structured and self._padded)
+            if self._compact is not None and not self._tree_blocks:
+                raise RuntimeError("block-compact W needs the per-row-block TSQR")
             self._block_cache = None
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
         if self._padded:
-            _lib.regressor_build_padded(handle, mode, flags | (_lib.FLAG_ZEROS_PRESENT if self._zeros_once else 0), ft_mask,
+            _lib.regressor_build_padded(handle, mode, flags | (_lib.FLAG_ZEROS_PRESENT if self._zeros_once else 0)
+                                        | (_lib.FLAG_COMPACT_BLOCKS if self._compact is not None else 0), ft_mask,
                                         self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         else:
             _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
@@ -313,14 +343,20 @@ class IdentificationPipeline:
             nf = self._nf_expected if split else 0
             nc = n + (1 if with_tau else 0)
             local = not getattr(ex, "collective", True)
-            blocks = self._block_lists(ncols, stride) if (getattr(self, "_tree_blocks", False) and nc > 80) else None
+            blocks = None
+            if getattr(self, "_tree_blocks", False) and (nc > 80 or self._compact is not None):
+                blocks = self._block_lists(ncols, stride)
+            if self._compact is not None and blocks is None and n > 0:
+                raise RuntimeError("block-compact W: no kept mask to build the column lists from")
             if split:
                 _lib.tsqr_selected_wrench(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, nf, self.d_tau,
                                           self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
             elif blocks is not None:
-                _lib.tsqr_selected_blocks(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, blocks[1], blocks[2],
-                                          blocks[3], self.d_tau, self.tol_qr if local else -1.0, self._d_sel,
-                                          self._d_rows if local else self._d_R)
+                coff, cld = self._compact if self._compact is not None else (None, None)
+                _lib.tsqr_selected_blocks(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, blocks[1],
+                                          blocks[4] if coff is not None else blocks[2], blocks[3], self.d_tau,
+                                          self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R,
+                                          block_off=coff, block_ld=cld)
             else:
                 _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
                                    self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
@@ -385,17 +421,33 @@ class IdentificationPipeline:
                 jid = parents[jid]
         kept = np.flatnonzero(mask)
         link, slot = kept // 14, kept % 14
-        counts, cols, pos = [], [], []
+        counts, cols, pos, ccols = [], [], [], []
         for j in range(nb):
             in_block = (anc[j][np.minimum(link, nb - 1)] & (link < nb) & (slot < 10)) | ((link == j) & (slot >= 10))
             p = np.flatnonzero(in_block)
             counts.append(len(p))
             pos.append(p)
             cols.append(link[p] * stride + slot[p])
-        d_cols = _lib.DeviceArray.from_host(np.concatenate(cols + [np.zeros(1, dtype=np.int64)]).astype(np.int32))
-        d_pos = _lib.DeviceArray.from_host(np.concatenate(pos + [np.zeros(1, dtype=np.int64)]).astype(np.int32))
-        self._block_cache = (mask.copy(), np.asarray(counts, dtype=np.int32), d_cols, d_pos)
+            ccols.append((link[p] - j) * 16 + slot[p])  # block-compact W: the row block starts at its own joint's link
+        pad = [np.zeros(1, dtype=np.int64)]
+        d_cols = _lib.DeviceArray.from_host(np.concatenate(cols + pad).astype(np.int32))
+        d_pos = _lib.DeviceArray.from_host(np.concatenate(pos + pad).astype(np.int32))
+        d_ccols = _lib.DeviceArray.from_host(np.concatenate(ccols + pad).astype(np.int32))
+        self._block_cache = (mask.copy(), np.asarray(counts, dtype=np.int32), d_cols, d_pos, d_ccols)
         return self._block_cache
+
+    def _subtree_sizes(self):
+        """Links in the subtree of every joint (depth-first numbering: the subtree of joint j + 1 is links j .. j + size - 1)."""
+        m = self.robot.model
+        nb = m.nv
+        parents = list(m.parents)
+        size = np.zeros(nb, dtype=np.int64)
+        for k in range(nb):
+            jid = k + 1
+            while jid > 0:
+                size[jid - 1] += 1
+                jid = parents[jid]
+        return size
 
     def _force_slots(self, ncols):
         """Mask over the reference's columns: slot >= 6 within a link (mx my mz m Ia fv fs off)."""

@@ -54,7 +54,14 @@ enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, 
         * entry that depends on q, v, a is written as always.  90 % of TIAGo's 73.7 GB are such zeros.  Not the default
         * of anything: a pass that re-creates every byte of W each time is what the pipeline and bench.py measure unless
         * asked otherwise. */
-       FIGH_FLAG_ZEROS_PRESENT = 1024 };
+       FIGH_FLAG_ZEROS_PRESENT = 1024,
+       /* figh_regressor_build_padded only: d_W is BLOCK-COMPACT -- the joint-torque regressor of a tree of single-dof joints
+        * stored row block by row block, block j (the N rows of joint j + 1) as its own N x ld_j matrix holding the columns
+        * of that joint's subtree (links j + 1 .. j + size_j, depth-first numbering: a contiguous window of the dense
+        * link-padded row, ld_j = 16 size_j) at element offset N * (ld_0 + .. + ld_{j-1}).  Everything outside the window is
+        * a structural zero that is neither stored nor read (figh_tsqr_selected_blocks with block offsets).  ldw is ignored;
+        * d_colsq keeps the reference's column numbering.  TIAGo: 7.9 instead of 73.7 GB per 1e6 samples. */
+       FIGH_FLAG_COMPACT_BLOCKS = 2048 };
 
 typedef struct figh_model_s *figh_model_t;
 
@@ -224,10 +231,13 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
  * entries are structural zeros.  Row block j (rows / nblocks rows) is factored over its own column list -- h_counts[j]
  * entries of d_cols (device column numbering) and d_pos (positions in the kept list), concatenated block after block,
  * built by the caller from the kept mask it expects (and verified against d_sel afterwards) -- reduced, embedded into the
- * kept column set, and the nblocks triangles are merged.  Same outputs as figh_tsqr_selected. */
+ * kept column set, and the nblocks triangles are merged.  Same outputs as figh_tsqr_selected.  h_block_off / h_block_ld
+ * (host, nblocks entries each, both or neither): the block-compact W of FIGH_FLAG_COMPACT_BLOCKS -- row block j is the
+ * rows / nblocks x h_block_ld[j] matrix at d_W + h_block_off[j] and d_cols index ITS columns; ldw is then unused. */
 int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nblocks, const int32_t *h_counts, const int32_t *d_cols,
-                              const int32_t *d_pos, const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out);
+                              const int32_t *d_pos, const int64_t *h_block_off, const int32_t *h_block_ld,
+                              const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out);
 /* figh_tsqr_merge followed by the rank decision and the regrouped factorisation as in figh_tsqr_selected (the cross-rank
  * reduction of the all-gathered per-rank triangles): columns k < n_free take part in the rank decision, the others (tau)
  * always count as base columns.  d_rows_out: (nc + 1) x nc. */

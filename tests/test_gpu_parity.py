@@ -704,7 +704,7 @@ def test_tree_row_blocks_column_lists(lib):
         out = pipe.run()
         if blocks:
             assert pipe._tree_blocks and pipe._block_cache is not None
-            mask, counts, d_cols, d_pos = pipe._block_cache
+            mask, counts, d_cols, d_pos = pipe._block_cache[:4]
             assert 0 < counts.max() < mask.sum() and counts.sum() < 0.3 * len(counts) * mask.sum()
             # the zero pattern of W against the lists (reference layout, a slice of the samples)
             W = build_regressor_basic(robot, q[:200], v[:200], a[:200], meta["param"])
@@ -726,6 +726,30 @@ def test_tree_row_blocks_column_lists(lib):
     assert a_["idx_e"] == b_["idx_e"] and a_["idx_base"] == b_["idx_base"] and a_["params_base"] == b_["params_base"]
     assert np.abs(a_["phi_ls"] - b_["phi_ls"]).max() <= 1e-8 * max(1.0, np.abs(b_["phi_ls"]).max())
     assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * max(1.0, b_["residual_norm"])
+    # (iii) block-compact W (FIGH_FLAG_COMPACT_BLOCKS): row block j stored as its own N x 16 |subtree_j| matrix; its content
+    # is the window of the dense link-padded row, bit for bit, and the pass gives the dense pass's results exactly
+    pipe_d = IdentificationPipeline(robot, meta["param"], params_std=dict(zip(meta["names_std"], meta["phi_ref_raw"])))
+    pipe_c = IdentificationPipeline(robot, meta["param"], params_std=dict(zip(meta["names_std"], meta["phi_ref_raw"])),
+                                    w_layout="block-compact")
+    res = []
+    for pipe in (pipe_d, pipe_c):
+        pipe.set_samples(q, v, a)
+        pipe.set_tau_from_parameters(np.array([float(x) for x in meta["phi_ref_raw"]]), noise_std=0.01, seed=3)
+        pipe.run()
+        res.append(pipe.run())
+    assert pipe_c._compact is not None and pipe_d._compact is None
+    N = len(q)
+    dense = pipe_d.W.buf.to_host().reshape(pipe_d.W.rows, pipe_d.W.ld)
+    comp = pipe_c.W.buf.to_host()
+    off, ld = pipe_c._compact
+    assert comp.size == N * ld.sum() and comp.size < 0.2 * dense.size
+    for j in range(len(ld)):
+        blk = comp[off[j]:off[j] + N * ld[j]].reshape(N, ld[j])
+        assert np.array_equal(blk, dense[j * N:(j + 1) * N, 16 * j:16 * j + ld[j]]), j
+        assert not dense[j * N:(j + 1) * N, :16 * j].any() and not dense[j * N:(j + 1) * N, 16 * j + ld[j]:].any()
+    for key in ("idx_e", "idx_base", "params_base"):
+        assert res[0][key] == res[1][key]
+    assert np.array_equal(res[0]["phi_ls"], res[1]["phi_ls"]) and np.array_equal(res[0]["col_norm"], res[1]["col_norm"])
 
 
 def test_structural_zeros_once_keeps_W_exact(lib):
