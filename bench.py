@@ -288,7 +288,7 @@ def main():
     n_kept = len(out["params_r"])
     kern = {}
     k1_name = "regressor_chain" if args.config == "cfg2" else "regressor_tree"
-    for name in (k1_name, "tsqr"):
+    for name in (k1_name, "tsqr", "fused_chain_tsqr"):
         cnt, ms = _lib.profile_get(name)
         if cnt:
             kern[name] = {"launches": cnt, "avg_ms": ms / cnt}

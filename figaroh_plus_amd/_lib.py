@@ -75,6 +75,9 @@ SIGNATURES = {
                                             C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "figh_regressor_tsqr_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double,
+                                            C.c_void_p]),
     "figh_tsqr_merge_base": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "figh_base_permutation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "figh_regressor_colsq": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
@@ -438,6 +441,17 @@ def tsqr_selected_blocks(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_e
                                            off.ctypes.data if off is not None else None,
                                            ld.ctypes.data if ld is not None else None,
                                            d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr, d_R.ptr))
+
+
+def regressor_tsqr_fused(model, flags, N, d_q, d_v, d_a, d_W, ldw, d_colsq, d_kept, n, d_tau, tol_qr, d_R):
+    """K1 + level-0 TSQR over the caller's kept-column list in one launch (serial chains, figh.h).  Returns False -- nothing
+    launched -- when the shape is not supported; raises on any other error."""
+    rc = load().figh_regressor_tsqr_fused(model.handle, flags, N, d_q.ptr, d_v.ptr, d_a.ptr, d_W.ptr, ldw, d_colsq.ptr,
+                                          d_kept.ptr, n, d_tau.ptr if d_tau is not None else None, tol_qr, d_R.ptr)
+    if rc == ERR_UNSUPPORTED:
+        return False
+    check(rc)
+    return True
 
 
 def tsqr_merge_base(d_Rs, count, nc, n_free, tol_qr, d_Rk):

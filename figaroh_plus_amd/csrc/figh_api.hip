@@ -92,7 +92,7 @@ static bool g_launch_events_taken = false;
 ProfileScope::ProfileScope(const char *name, bool at_launch) : name_(name), at_launch_(at_launch) {
     if (!g_profile) return;
     if (g_profile == 1 && std::strcmp(name, "regressor_chain") != 0 && std::strcmp(name, "regressor_tree") != 0 &&
-        std::strcmp(name, "tsqr") != 0)
+        std::strcmp(name, "tsqr") != 0 && std::strcmp(name, "fused_chain_tsqr") != 0)
         return;
     e0_ = acquire_event();
     e1_ = acquire_event();

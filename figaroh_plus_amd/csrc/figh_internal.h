@@ -101,6 +101,9 @@ void tsqr_level0_chain(long wgs, int chain_flags);
 // in force rows (d_fsel: n columns, then n positions in the kept list) and the force rows' triangle over all kept columns
 int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel);
 int embed_force_triangle(const double *d_Rf, int ncf, int nf, const int *d_fpos, int nc, int n, double *d_out);
+// figh_linalg.hip: stack of `count` compact nc x nc triangles -> one; tol_qr >= 0: + rank decision and regrouped rows
+// ((nc + 1) x nc doubles, layout in figh.h, figh_tsqr_selected), else the plain triangle
+int tsqr_reduce_stack(const double *d_Rs, long count, int nc, int n_free, double tol_qr, double *d_out);
 // figh_tsqr_wide_pair.hip: one pair-merge level, `count` stacked triangles -> (count + 1) / 2
 int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_out);
 int launch_tsqr_wide_single(const double *W, long rows, long ldw, const int *col_idx, int n, int nc, double *R_out);

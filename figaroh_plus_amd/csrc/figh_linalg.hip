@@ -25,127 +25,10 @@
 
 #include "figh_internal.h"
 #include "figh_wave.h"
+#include "figh_tsqr_narrow.h"
 
 namespace figh {
 
-// ------------------------------------------------------------------------------------------------------------
-// tsqr2_kernel<NCC, NRC>: the n <= 16*NCC (<= 80) kernel.  The 16*NRC x 16*NCC tile sits in registers in the
-// MFMA f64 C/D layout (figh_wave.h).  A column step needs
-//   - the pivot column inside each row group: a DPP row_newbcast operand of v_fmac_f64 (no LDS crossbar),
-//   - the dot products summed over the four row groups: 512 B of wave-private LDS,
-// instead of 128 ds_bpermute per step (6.2 cycles each per CU, shared by the four SIMDs).  Finished chunks drop out
-// of the update loops (the triangle's zero part costs nothing).
-template <int NCC, int NRC>
-struct Tsqr2State {
-    static constexpr int RPL = 4 * NRC;  // rows per lane
-    double T[NCC][RPL];
-    double *Rl;   // LDS triangle (packed, biased so that the compile-time row offsets apply)
-    double *red;  // LDS: 64 doubles of cross-row-group reduction scratch, private to the wave
-    int lane_c;   // lane & 15
-    int lane_g;   // lane >> 4
-    int nc;
-};
-
-// The panel index P is a compile-time constant: the chunk registers T[P .. NCC-1] are addressed statically (no
-// rotation copies), the number of live chunks is known, and a step is straight-line code -- after the pivot chunk's
-// own dot product (the only input of the Householder scalars) the dot products of the trailing chunks and the LDS
-// reads of row k are independent of the rsq/rcp chain and are interleaved with it by the scheduler.
-
-template <bool LDSRED, int NCC, int NRC>
-__device__ __forceinline__ double tsqr2_reduce(Tsqr2State<NCC, NRC> &S, const double x) {
-    if constexpr (LDSRED) return allreduce_rowgroups_lds(S.red, 16 * S.lane_g + S.lane_c, x);
-    else return allreduce_rowgroups(x);
-}
-
-template <int KK, int P, int NCC, int NRC, bool LDSRED>
-__device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC> &S) {
-    constexpr int RPL = 4 * NRC;
-    constexpr int LIVE = NCC - P;
-    constexpr int NR = RPL;
-    // packed triangle: panel p keeps 16 rows of 16*(NCC-p) entries (columns 16p ..)
-    constexpr int rowoff = 256 * (P * NCC - (P * (P - 1)) / 2) + KK * 16 * LIVE;
-    // The pivot column x = lane-column KK of chunk P is read in place through the DPP operand.
-    double Rk[LIVE], d[LIVE];
-#pragma unroll
-    for (int cc = 0; cc < LIVE; ++cc) Rk[cc] = S.Rl[rowoff + 16 * cc + S.lane_c];
-    // the diagonal entry R_kk straight from LDS (one address for the whole wave: a broadcast read on the LDS port)
-    // instead of a v_mov_b64_dpp of Rk[0] on the VALU (8 ticks)
-    double alpha = S.Rl[rowoff + KK];
-    {
-        double s0 = 0.0, s1 = 0.0;  // two chains (the second wave of the SIMD covers the FMA latency): 2 movs + 1 add
-#pragma unroll
-        for (int i = 0; i < NR; i += 2) {
-            fmac_bcast<KK>(s0, S.T[P][i], S.T[P][i]);
-            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P][i + 1]);
-        }
-        d[0] = tsqr2_reduce<LDSRED>(S, s0 + s1);
-    }
-    // row k of the triangle is requested before the dot product and pinned here, so that the LDS latency is not
-    // part of the dependent chain below (the compiler would otherwise sink the read below the sigma branch)
-#pragma unroll
-    for (int cc = 0; cc < LIVE; ++cc) asm volatile("" : "+v"(Rk[cc]));
-    asm volatile("" : "+v"(alpha));
-    const double sigma = row_bcast<KK>(d[0]);
-    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
-    // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
-    // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds (~2^-24) + ONE third-order step each
-    // (y (1 + e/2 + 3e^2/8), e = 1 - q y^2: error e^3; r (1 + e + e^2), e = 1 - d r) instead of two Newton steps:
-    // 5 + 3 dependent operations instead of 7 + 4
-    const double q2 = fma(alpha, alpha, sigma);
-    double rs = __builtin_amdgcn_rsq(q2);
-    {
-        const double e = fma(-(q2 * rs), rs, 1.0);
-        rs = fma(rs, fma(e, 0.375, 0.5) * e, rs);
-    }
-    const double dsum = fma(q2, rs, fabs(alpha));  // |alpha| + s
-    double ri = __builtin_amdgcn_rcp(dsum);
-    {
-        const double e = fma(-dsum, ri, 1.0);
-        ri = fma(ri, fma(e, e, e), ri);
-    }
-    const double inv = copysign(ri, alpha);
-    const double tfac = dsum * rs;
-#pragma unroll
-    for (int cc = 1; cc < LIVE; ++cc) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NR; i += 2) {
-            fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
-            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
-        }
-        d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
-    }
-    // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
-    //   - the pivot lane itself gets w = (alpha + sigma inv) tfac = alpha - beta, hence R_kk = alpha - w = beta and
-    //     c = w inv = 1: its tile entries x - 1 x vanish (the finished column leaves the tile);
-    //   - finished lane-columns (c < KK) and padding hold zeros (up to rounding residues that are never read as
-    //     results), so their w is zero by itself.
-    // Trailing chunks first, the pivot chunk last: its own update is the only write to the DPP source registers.
-#pragma unroll
-    for (int cc = LIVE - 1; cc >= 0; --cc) {
-        const double wj = (Rk[cc] + d[cc] * inv) * tfac;
-        const double ncj = -wj * inv;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) fmac_bcast<KK>(S.T[P + cc][i], S.T[P][i], ncj);
-        if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = Rk[cc] - wj;
-    }
-}
-
-// all column steps of panel P, then the next panel (compile-time recursion over the panels).  after(P) runs when
-// chunk P is retired (its registers are dead for the rest of the tile): the kernel requests the next tile's chunk P
-// into them there.
-template <int P, int NCC, int NRC, bool LDSRED, class AfterPanel>
-__device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC> &S, const int first_nz, AfterPanel &&after) {
-    if (16 * P + 15 >= first_nz) {
-#define FIGH_STEP(KK) \
-    if (16 * P + KK >= first_nz) tsqr2_step<KK, P, NCC, NRC, LDSRED>(S);
-        FIGH_STEP(0) FIGH_STEP(1) FIGH_STEP(2) FIGH_STEP(3) FIGH_STEP(4) FIGH_STEP(5) FIGH_STEP(6) FIGH_STEP(7)
-        FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
-#undef FIGH_STEP
-    }
-    after(std::integral_constant<int, P>{});
-    if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, LDSRED>(S, first_nz, after);
-}
 
 template <int NCC, int NRC, bool LDSRED>
 __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
@@ -1110,8 +993,10 @@ static int reveal_triangle(const double *d_R, int nc, int n_free, double tol_qr,
     return FIGH_OK;
 }
 
+}  // extern "C"
+
 // stack of `count` triangles -> one; tol_qr >= 0: + rank decision and regrouped rows ((nc+1) x nc), else the plain triangle
-static int reduce_stack(const double *d_Rs, long count, int nc, int n_free, double tol_qr, double *d_out) {
+int figh::tsqr_reduce_stack(const double *d_Rs, long count, int nc, int n_free, double tol_qr, double *d_out) {
     if (tol_qr < 0.0) return figh_tsqr_merge(d_Rs, (int)count, nc, d_out);
     double *one = static_cast<double *>(workspace(sizeof(double) * (size_t)nc * nc, 16));
     if (!one) return FIGH_ERR_ALLOC;
@@ -1128,6 +1013,8 @@ static int reduce_stack(const double *d_Rs, long count, int nc, int n_free, doub
     if (int rc = tsqr_reduce(d_Rs, count, nc, one)) return rc;
     return reveal_triangle(one, nc, n_free, tol_qr, d_out);
 }
+
+extern "C" {
 
 int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                        int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
@@ -1163,7 +1050,7 @@ int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const doubl
     const int rc0 = figh_tsqr_level0(d_W, rows, ldw, d_sel + 2, n_expected, d_tau, nullptr, 0, nullptr, 0, &nw, &Rws);
     g_tile_hint = nullptr;
     if (rc0) return rc0;
-    return reduce_stack(Rws, nw, nc, n_expected, tol_qr, d_R_out);
+    return tsqr_reduce_stack(Rws, nw, nc, n_expected, tol_qr, d_R_out);
 }
 
 // figh_tsqr_selected for the external-wrench regressor of a free-flyer model (six row blocks of rows / 6 rows: three force
@@ -1227,7 +1114,7 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
     hipLaunchKernelGGL(embed_force_triangle_kernel, dim3(1), dim3(1024), 0, stream(), Rf, ncf, nf, fsel + n, nc, n,
                        stack + (size_t)cnt * nc * nc);
     FIGH_HIP(hipGetLastError());
-    return reduce_stack(stack, cnt + 1, nc, n, tol_qr, d_R_out);
+    return tsqr_reduce_stack(stack, cnt + 1, nc, n, tol_qr, d_R_out);
 }
 
 // figh_tsqr_selected for the joint-torque regressor of a TREE of single-dof joints (regressor.py:45-87): row block j (the
@@ -1297,7 +1184,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         FIGH_HIP(hipMemsetAsync(stack, 0, tri, stream()));
         have = 1;
     }
-    return reduce_stack(stack, have, nc, n, tol_qr, d_R_out);
+    return tsqr_reduce_stack(stack, have, nc, n, tol_qr, d_R_out);
 }
 
 int figh_tsqr_merge_base(const double *d_Rs, int count, int nc, int n_free, double tol_qr, double *d_Rk_out) {
@@ -1305,7 +1192,7 @@ int figh_tsqr_merge_base(const double *d_Rs, int count, int nc, int n_free, doub
     FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 512 && n_free >= 1 && n_free <= nc, "bad shape");
     FIGH_REQUIRE(tol_qr >= 0.0, "tol_qr must be non-negative");
     if (int rc = ensure_device()) return rc;
-    return reduce_stack(d_Rs, count, nc, n_free, tol_qr, d_Rk_out);
+    return tsqr_reduce_stack(d_Rs, count, nc, n_free, tol_qr, d_Rk_out);
 }
 
 }  // extern "C"

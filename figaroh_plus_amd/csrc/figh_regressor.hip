@@ -28,6 +28,7 @@
 
 #include "figh_internal.h"
 #include "figh_spatial.h"
+#include "figh_chain.h"
 
 namespace figh {
 
@@ -36,22 +37,6 @@ namespace figh {
 __device__ int g_chain_hotin = 0;
 __device__ int g_chain_blocked = 0;
 #endif
-
-template <int NJ>
-struct ChainParams {
-    double axis[NJ][3];
-    double Rp[NJ][9];
-    double pp[NJ][3];
-    double g[3];
-};
-
-template <int NJ, bool TX40>
-struct ChainGeom {
-    static constexpr int NC = 14 * NJ + (TX40 ? 3 : 0);
-    static constexpr int VEC = (NC % 2 == 0) ? 2 : 1;       // doubles per store
-    static constexpr int LDT = (NC % 2 == 0) ? NC + 2 : NC;  // LDS row stride (doubles)
-    static constexpr int CH = NC / VEC;                       // store chunks per row
-};
 
 // FIGAROH slot of Pinocchio inertia entry: [xx xy yy xz yz zz] -> Ixx Ixy Ixz Iyy Iyz Izz = slots 0 1 3 2 4 5
 template <int NJ, bool TX40, bool COLSQ>

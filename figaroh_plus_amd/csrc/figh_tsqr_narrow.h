@@ -1,0 +1,158 @@
+// Column steps of the register-tile TSQR (n <= 16*NCC <= 80 columns), shared by tsqr2_kernel (figh_linalg.hip) and the
+// fused regressor + TSQR kernel (figh_fused.hip).
+#pragma once
+
+#include <type_traits>
+
+#include "figh_wave.h"
+
+namespace figh {
+
+// ------------------------------------------------------------------------------------------------------------
+// tsqr2_kernel<NCC, NRC>: the n <= 16*NCC (<= 80) kernel.  The 16*NRC x 16*NCC tile sits in registers in the
+// MFMA f64 C/D layout (figh_wave.h).  A column step needs
+//   - the pivot column inside each row group: a DPP row_newbcast operand of v_fmac_f64 (no LDS crossbar),
+//   - the dot products summed over the four row groups: 512 B of wave-private LDS,
+// instead of 128 ds_bpermute per step (6.2 cycles each per CU, shared by the four SIMDs).  Finished chunks drop out
+// of the update loops (the triangle's zero part costs nothing).
+//
+// RLAST (the fused kernel, figh_fused.hip: LDS is what limits the number of waves there): the last 16 lane-columns of the
+// triangle live in REGISTERS -- row kp of that chunk in the lanes of row group kp % 4, register kp / 4 -- and only the other
+// NCC - 1 chunks in LDS (7.4 KB instead of 13.8 KB for 50 columns).  A step passes its row of the register chunk to the
+// other row groups through 128 B of LDS scratch (one masked ds_write + one ds_read, where the LDS form has a read and a
+// masked write of the row itself).
+template <int NCC, int NRC, bool RLAST = false>
+struct Tsqr2State {
+    static constexpr int RPL = 4 * NRC;  // rows per lane
+    double T[NCC][RPL];
+    double Rq[RLAST ? 4 * NCC : 1];  // RLAST: rows 4 s + lane_g of the last chunk's triangle columns
+    double *Rl;   // LDS triangle (packed, biased so that the compile-time row offsets apply)
+    double *red;  // LDS: 64 doubles of cross-row-group reduction scratch, private to the wave
+    double *bc;   // RLAST: 16 doubles of LDS, the current row of the register chunk for all row groups
+    int lane_c;   // lane & 15
+    int lane_g;   // lane >> 4
+    int nc;
+};
+
+// doubles of LDS in front of row 0 of panel P in the packed triangle (LCH chunks per row of panel 0)
+template <int LCH>
+constexpr int tsqr2_panel_off(int P) { return 256 * (P * LCH - (P * (P - 1)) / 2); }
+
+// The panel index P is a compile-time constant: the chunk registers T[P .. NCC-1] are addressed statically (no
+// rotation copies), the number of live chunks is known, and a step is straight-line code -- after the pivot chunk's
+// own dot product (the only input of the Householder scalars) the dot products of the trailing chunks and the LDS
+// reads of row k are independent of the rsq/rcp chain and are interleaved with it by the scheduler.
+
+template <bool LDSRED, int NCC, int NRC, bool RLAST>
+__device__ __forceinline__ double tsqr2_reduce(Tsqr2State<NCC, NRC, RLAST> &S, const double x) {
+    if constexpr (LDSRED) return allreduce_rowgroups_lds(S.red, 16 * S.lane_g + S.lane_c, x);
+    else return allreduce_rowgroups(x);
+}
+
+template <int KK, int P, int NCC, int NRC, bool LDSRED, bool RLAST = false>
+__device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
+    constexpr int RPL = 4 * NRC;
+    constexpr int LIVE = NCC - P;
+    constexpr int NR = RPL;
+    constexpr int LCH = RLAST ? NCC - 1 : NCC;  // chunks of the triangle kept in LDS
+    constexpr int LLIVE = LCH - P;              // ... of which live in this panel (RLAST, last panel: none)
+    // packed triangle: panel p keeps 16 rows of 16*(LCH-p) entries (columns 16p ..)
+    constexpr int rowoff = tsqr2_panel_off<LCH>(P) + KK * 16 * LLIVE;
+    constexpr int g0 = KK & 3, slot = 4 * P + (KK >> 2);  // RLAST: row 16 P + KK of the register chunk
+    // The pivot column x = lane-column KK of chunk P is read in place through the DPP operand.
+    double Rk[LIVE], d[LIVE];
+    if constexpr (RLAST) {
+        if (S.lane_g == g0) S.bc[S.lane_c] = S.Rq[slot];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Rk[LIVE - 1] = S.bc[S.lane_c];
+    }
+#pragma unroll
+    for (int cc = 0; cc < LLIVE; ++cc) Rk[cc] = S.Rl[rowoff + 16 * cc + S.lane_c];
+    // the diagonal entry R_kk straight from LDS (one address for the whole wave: a broadcast read on the LDS port)
+    // instead of a v_mov_b64_dpp of Rk[0] on the VALU (8 ticks)
+    double alpha;
+    if constexpr (RLAST && LLIVE == 0) alpha = S.bc[KK];
+    else alpha = S.Rl[rowoff + KK];
+    {
+        double s0 = 0.0, s1 = 0.0;  // two chains (the second wave of the SIMD covers the FMA latency): 2 movs + 1 add
+#pragma unroll
+        for (int i = 0; i < NR; i += 2) {
+            fmac_bcast<KK>(s0, S.T[P][i], S.T[P][i]);
+            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P][i + 1]);
+        }
+        d[0] = tsqr2_reduce<LDSRED>(S, s0 + s1);
+    }
+    // row k of the triangle is requested before the dot product and pinned here, so that the LDS latency is not
+    // part of the dependent chain below (the compiler would otherwise sink the read below the sigma branch)
+#pragma unroll
+    for (int cc = 0; cc < LIVE; ++cc) asm volatile("" : "+v"(Rk[cc]));
+    asm volatile("" : "+v"(alpha));
+    const double sigma = row_bcast<KK>(d[0]);
+    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
+    // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
+    // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds (~2^-24) + ONE third-order step each
+    // (y (1 + e/2 + 3e^2/8), e = 1 - q y^2: error e^3; r (1 + e + e^2), e = 1 - d r) instead of two Newton steps:
+    // 5 + 3 dependent operations instead of 7 + 4
+    const double q2 = fma(alpha, alpha, sigma);
+    double rs = __builtin_amdgcn_rsq(q2);
+    {
+        const double e = fma(-(q2 * rs), rs, 1.0);
+        rs = fma(rs, fma(e, 0.375, 0.5) * e, rs);
+    }
+    const double dsum = fma(q2, rs, fabs(alpha));  // |alpha| + s
+    double ri = __builtin_amdgcn_rcp(dsum);
+    {
+        const double e = fma(-dsum, ri, 1.0);
+        ri = fma(ri, fma(e, e, e), ri);
+    }
+    const double inv = copysign(ri, alpha);
+    const double tfac = dsum * rs;
+#pragma unroll
+    for (int cc = 1; cc < LIVE; ++cc) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; i += 2) {
+            fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
+            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
+        }
+        d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
+    }
+    // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
+    //   - the pivot lane itself gets w = (alpha + sigma inv) tfac = alpha - beta, hence R_kk = alpha - w = beta and
+    //     c = w inv = 1: its tile entries x - 1 x vanish (the finished column leaves the tile);
+    //   - finished lane-columns (c < KK) and padding hold zeros (up to rounding residues that are never read as
+    //     results), so their w is zero by itself.
+    // Trailing chunks first, the pivot chunk last: its own update is the only write to the DPP source registers.
+#pragma unroll
+    for (int cc = LIVE - 1; cc >= 0; --cc) {
+        const double wj = (Rk[cc] + d[cc] * inv) * tfac;
+        const double ncj = -wj * inv;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) fmac_bcast<KK>(S.T[P + cc][i], S.T[P][i], ncj);
+        if (RLAST && cc == LIVE - 1) {
+            if (S.lane_g == g0) S.Rq[slot] = Rk[cc] - wj;
+        } else {
+            if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = Rk[cc] - wj;
+        }
+    }
+}
+
+// all column steps of panel P, then the next panel (compile-time recursion over the panels).  after(P) runs when
+// chunk P is retired (its registers are dead for the rest of the tile): the kernel requests the next tile's chunk P
+// into them there.
+template <int P, int NCC, int NRC, bool LDSRED, bool RLAST = false, class AfterPanel>
+__device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC, RLAST> &S, const int first_nz, AfterPanel &&after) {
+    if (16 * P + 15 >= first_nz) {
+#define FIGH_STEP(KK) \
+    if (16 * P + KK >= first_nz) tsqr2_step<KK, P, NCC, NRC, LDSRED, RLAST>(S);
+        FIGH_STEP(0) FIGH_STEP(1) FIGH_STEP(2) FIGH_STEP(3) FIGH_STEP(4) FIGH_STEP(5) FIGH_STEP(6) FIGH_STEP(7)
+        FIGH_STEP(8) FIGH_STEP(9) FIGH_STEP(10) FIGH_STEP(11) FIGH_STEP(12) FIGH_STEP(13) FIGH_STEP(14) FIGH_STEP(15)
+#undef FIGH_STEP
+    }
+    after(std::integral_constant<int, P>{});
+    if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, LDSRED, RLAST>(S, first_nz, after);
+}
+
+}  // namespace figh

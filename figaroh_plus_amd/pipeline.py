@@ -70,12 +70,19 @@ def _solve_upper(R1, B):
 
 class IdentificationPipeline:
     def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
-                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass", w_layout="dense"):
+                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass", w_layout="dense", fuse=True):
         """``chunk_samples``: when the stacked regressor of all N samples does not fit HBM (human model at 1e7
         samples: 269 GB) the samples are processed in chunks of this size -- pass 1 accumulates diag(W^T W), pass 2
         rebuilds each chunk's W (recomputing is far cheaper than storing), factors it and stacks the triangles,
         which ``figh_tsqr_merge`` reduces.  Results are those of the one-shot pass (R is row-order independent)."""
         self.chunk_samples = chunk_samples
+        # fuse (serial chains, W in the reference layout): from the second pass on K1 and the level-0 TSQR run as ONE launch
+        # (figh_regressor_tsqr_fused) over the kept-column list of the previous pass -- every 64-row tile of W is factored
+        # while it is still in LDS, W is written but not read back.  The list is verified against the norms the pass produces;
+        # a pass whose kept set changed falls back to the two launches below (and learns the new list).
+        self.fuse = bool(fuse)
+        self._fused_kept = None
+        self.fused_passes = 0
         # structural_zeros = "once" (opt-in, joint-torque regressor of a tree kept in HBM): W is zero-filled when it is
         # allocated and the regressor kernel is told that the structural zeros are present (FIGH_FLAG_ZEROS_PRESENT) -- it
         # rewrites every entry that depends on q, v, a in every pass and leaves the zeros alone.  The default re-creates
@@ -328,6 +335,10 @@ class IdentificationPipeline:
                 raise RuntimeError("block-compact W needs the per-row-block TSQR")
             self._block_cache = None
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
+        if self.fuse and self._fused_kept is not None and not self._padded:
+            out = self._run_fused(handle, flags, strings)
+            if out is not None:
+                return out
         if self._padded:
             _lib.regressor_build_padded(handle, mode, flags | (_lib.FLAG_ZEROS_PRESENT if self._zeros_once else 0)
                                         | (_lib.FLAG_COMPACT_BLOCKS if self._compact is not None else 0), ft_mask,
@@ -397,7 +408,53 @@ class IdentificationPipeline:
             params_r = [self.names[i] for i in np.flatnonzero(kept_mask).tolist()]
             self._kept_cache = (kept_mask.copy(), list(idx_e), list(params_r))
         rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
+        if self.fuse and not self._padded and self._compact is None and (
+                self._fused_kept is None or not np.array_equal(self._fused_kept[0], kept_mask)):
+            kept = np.flatnonzero(kept_mask).astype(np.int32)
+            self._fused_kept = (kept_mask.copy(), _lib.DeviceArray.from_host(kept), len(kept))
         return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+
+    def _run_fused(self, handle, flags, strings):
+        """One pass with K1 and the level-0 TSQR in one launch over the kept-column list of the previous pass
+        (figh_regressor_tsqr_fused).  Returns None -- the caller takes the two-launch path -- when the shape is not supported
+        or the kept set turned out to be different."""
+        ex, lib, W = self.exchange, _lib.load(), self.W
+        mask, d_kept, n = self._fused_kept
+        ncols, with_tau = W.ref_cols, self.d_tau is not None
+        nc = n + (1 if with_tau else 0)
+        local = not getattr(ex, "collective", True)
+        if not _lib.regressor_tsqr_fused(handle, flags, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, self._d_colsq,
+                                         d_kept, n, self.d_tau, self.tol_qr if local else -1.0,
+                                         self._d_rows if local else self._d_R):
+            self.fuse = False  # (this shape never fuses: do not ask again)
+            return None
+        ex.sum_columns_device(self._d_colsq, ncols)
+        _lib.select_columns(self._d_colsq, ncols, self.tol_e, 14, self._d_sel)
+        if not local:
+            d_stack, count = ex.stack_triangles(self._d_R, nc)
+            _lib.tsqr_merge_base(d_stack, count, nc, n, self.tol_qr, self._d_rows)
+        words = ncols + self._sel_words + (nc + 1) * nc
+        pin = getattr(self, "_host_pack", None)
+        if pin is None or pin.size < self._d_pack.size:
+            pin = self._host_pack = _lib.PinnedArray(self._d_pack.size)
+        host = pin.array[:words]
+        _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, self._d_pack.ptr, host.nbytes))
+        sel = host[ncols:ncols + self._sel_words].view(np.int32)
+        mask_now = sel[2 + ncols:2 + 2 * ncols] != 0
+        if not np.array_equal(mask_now, mask):
+            self._fused_kept = None  # the kept set changed: the two-launch path learns the new one
+            return None
+        self.fused_passes += 1
+        self._n_expected = n
+        cached = self._kept_cache
+        if cached is not None and np.array_equal(cached[0], mask):
+            idx_e, params_r = list(cached[1]), list(cached[2])
+        else:
+            idx_e = np.flatnonzero(~mask).tolist()
+            params_r = [self.names[i] for i in np.flatnonzero(mask).tolist()]
+            self._kept_cache = (mask.copy(), list(idx_e), list(params_r))
+        rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
+        return self._finish(rows_k, n, nc, params_r, idx_e, host[:ncols].copy(), with_tau, W.rows * ex.world_size, strings)
 
     def _block_lists(self, ncols, stride):
         """(mask, counts, d_cols, d_pos) for figh_tsqr_selected_blocks, from the kept mask this pass expects: row block j

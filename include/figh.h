@@ -216,6 +216,21 @@ int figh_select_columns(const double *d_colsq, int ncols, double tol_e, int link
 int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                        int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
                        double *d_R_out);
+/* figh_regressor_build (+ column norms) and the level-0 TSQR of W[:, d_kept] [+ tau] in ONE launch, for fixed-base serial
+ * chains in joint-torque mode (UR10; regressor.py:20-194 with the pin.computeJointTorqueRegressor loop :45-87,
+ * get_index_eliminate's norms :258-279, np.linalg.qr of get_baseParams qrdecomposition.py:205): W is written to HBM exactly
+ * as figh_regressor_build writes it (ldw must equal the column count, d_W 16-byte aligned), d_colsq receives diag(W^T W),
+ * and every 64-row tile is factored while it is still in the LDS of the CU that produced it -- the TSQR does not read W
+ * back.  d_kept: the n kept columns (reference numbering, ascending) the caller expects -- those of the previous pass; the
+ * caller verifies them afterwards against d_colsq (figh_select_columns) and repeats the pass through figh_regressor_build +
+ * figh_tsqr_selected on a mismatch.  d_R_out as in figh_tsqr_selected (tol_qr < 0: the plain nc x nc triangle; tol_qr >= 0:
+ * (nc + 1) x nc rows of the regrouped factorisation + the plain diagonal).  The tiles of a CU are handed to whichever
+ * consumer wave is free, so R is reproduced up to rounding (not bit for bit) from run to run; W and d_colsq are
+ * bit-reproducible.  FIGH_ERR_UNSUPPORTED (nothing launched): not a 6-joint chain, TX40 coupling columns, more than 64
+ * columns with tau, fewer than 4096 samples, padded or unaligned W. */
+int figh_regressor_tsqr_fused(figh_model_t model, int flags, int64_t N, const double *d_q, const double *d_v,
+                              const double *d_a, double *d_W, int64_t ldw, double *d_colsq, const int32_t *d_kept, int n,
+                              const double *d_tau, double tol_qr, double *d_R_out);
 /* figh_tsqr_selected for the external-wrench regressor of a model with a free-flyer root (regressor.py:89-192: six row
  * blocks of rows / 6 rows, force components first): in the force rows the six rotational-inertia columns of every link
  * are exact zeros, so those rows are factored over the nf_expected kept columns with slot >= 6 only (2 m nf^2 instead of

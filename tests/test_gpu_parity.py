@@ -1615,3 +1615,94 @@ def test_tree_regressor_blocked_inputs_identical(lib, golden):
         with pytest.raises(lib.FighError):  # the chain kernel keeps the original arrays
             lib.regressor_build(dm, mode, (flags & ~lib.FLAG_GENERIC) | lib.FLAG_BLOCKED_INPUTS, ft, N, bq, bv, ba,
                                 lib.DeviceArray((rps * N * ncols,)), ncols, None)
+
+
+# ------------------------------------------------------------------------------------------------ fused K1 + TSQR
+def _ur10_problem(g, N, seed, noise=0.05):
+    rng = np.random.default_rng(seed)
+    q, v, a = (rng.uniform(-6, 6, (N, 6)) for _ in range(3))
+    return q, v, a, rng, noise
+
+
+@pytest.mark.parametrize("N", [4096, 20000, 20037, 131072 + 5])
+def test_fused_pass_equals_two_launch_pass(lib, golden_ur10, N):
+    """figh_regressor_tsqr_fused (K1 + level-0 TSQR in one launch, tiles factored out of LDS) against the two-launch pass on
+    the same samples: W to a few ulp with the identical zero pattern, diag(W^T W) to 1e-13, identical index sets and expressions, R up to rounding (the tiles of a CU go to
+    whichever consumer wave is free: the grouping of rows into triangles differs from the two-launch kernel's and from run
+    to run), phi to 1e-9."""
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    g = golden_ur10
+    q, v, a, rng, noise = _ur10_problem(g, N, 77 + N)
+    phi = g.phi_ref()
+    outs, Ws, pipes = [], [], []
+    for fuse in (False, True):
+        pipe = IdentificationPipeline(g.robot(), g.param, params_std=g.params_std(), coupling=g.coupling, fuse=fuse)
+        pipe.set_samples(q, v, a)
+        pipe.set_tau_from_parameters(phi, noise_std=noise, seed=3)
+        pipe.run()
+        # poison W: the second pass must re-create every byte
+        lib.check(lib.load().figh_memset(pipe.W.buf.ptr, 0xff, pipe.W.rows * pipe.W.ld * 8))
+        out = pipe.run()
+        assert pipe.fused_passes == (1 if fuse else 0)
+        W = np.empty((pipe.W.rows, pipe.W.ld))
+        lib.check(lib.load().figh_memcpy_d2h(W.ctypes.data, pipe.W.buf.ptr, W.nbytes))
+        outs.append(out)
+        Ws.append(W)
+        pipes.append(pipe)
+    a_, b_ = outs
+    # the same formulas, compiled in another context (the fused producer re-forms the link rotations per row where the
+    # two-launch kernel keeps them): products are contracted differently here and there, entries agree to a few ulp
+    assert np.abs(Ws[0] - Ws[1]).max() <= 4e-16 * np.abs(Ws[0]).max(), "fused W differs from the two-launch W"
+    assert np.array_equal(Ws[0] == 0.0, Ws[1] == 0.0)
+    assert np.abs(a_["col_norm"] - b_["col_norm"]).max() <= 1e-13 * a_["col_norm"].max()
+    assert a_["idx_e"] == b_["idx_e"] == list(g["idx_e"])
+    assert a_["params_r"] == b_["params_r"]
+    assert a_["idx_base"] == b_["idx_base"] == list(g["idx_base"])
+    assert a_["params_base"] == b_["params_base"] == g.meta["params_base"]
+    # |R_kk| is unique up to the first dependent column only (behind it no two Householder orders agree, DESIGN.md)
+    first_dep = min(i for i in range(len(a_["params_r"])) if i not in set(a_["idx_base"]))
+    d_a, d_b = a_["absdiagR"][:first_dep], b_["absdiagR"][:first_dep]
+    assert np.abs(d_a - d_b).max() <= 1e-11 * d_a.max()
+    assert np.abs(a_["phi_ls"] - b_["phi_ls"]).max() <= 1e-9 * np.abs(a_["phi_ls"]).max()
+    assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-11 * a_["residual_norm"]
+    assert np.array_equal(a_["beta"], b_["beta"])
+    # a third pass: fused again, same results up to rounding
+    c_ = pipes[1].run()
+    assert pipes[1].fused_passes == 2
+    assert c_["idx_base"] == b_["idx_base"] and np.abs(c_["phi_ls"] - b_["phi_ls"]).max() <= 1e-10 * np.abs(b_["phi_ls"]).max()
+
+
+def test_fused_pass_triangle_against_lapack(lib, golden_ur10, oracle_lib):
+    """The plain triangle of the fused launch (tol_qr < 0) against LAPACK's R of the oracle's [W_e tau]: R^T R to 1e-12."""
+    g = golden_ur10
+    N = 8192 + 17
+    q, v, a, rng, _ = _ur10_problem(g, N, 5)
+    W_ref = _oracle_W(g, oracle_lib, q, v, a)
+    tau = rng.standard_normal(6 * N)
+    kept = np.array([c for c in range(84) if c not in set(int(x) for x in g["idx_e"])], dtype=np.int32)
+    n, nc = len(kept), len(kept) + 1
+    from figaroh_plus_amd.tools.regressor import _samples_to_device
+    robot = g.robot()
+    _, d_q, d_v, d_a = _samples_to_device(robot.model, q, v, a)
+    d_W = lib.DeviceArray((6 * N * 84,), np.float64)
+    d_cs = lib.DeviceArray((84,), np.float64)
+    d_kept = lib.DeviceArray.from_host(kept)
+    d_tau = lib.DeviceArray.from_host(tau)
+    d_R = lib.DeviceArray((nc * nc,), np.float64)
+    assert lib.regressor_tsqr_fused(robot.device_model(), 0, N, d_q, d_v, d_a, d_W, 84, d_cs, d_kept, n, d_tau, -1.0, d_R)
+    R = d_R.to_host().reshape(nc, nc)
+    W = d_W.to_host().reshape(6 * N, 84)
+    assert np.abs(W - W_ref).max() <= 1e-12 * np.abs(W_ref).max()
+    # zero pattern: on these random samples the closed-form rows leave residues of 1e-15 in three columns of link 2 where
+    # the oracle's literal propagation cancels exactly (the two-launch kernel does the same); nothing larger than that
+    assert np.abs(W[W_ref == 0]).max(initial=0.0) <= 1e-14 * np.abs(W_ref).max()
+    assert np.abs(W_ref[W == 0]).max(initial=0.0) <= 1e-14 * np.abs(W_ref).max()
+    A = np.c_[W_ref[:, kept], tau]
+    G = A.T @ A
+    assert np.abs(R.T @ R - G).max() <= 1e-12 * np.abs(G).max()
+    assert np.abs(np.tril(R, -1)).max() == 0.0
+    cs = d_cs.to_host()
+    ref = (W_ref * W_ref).sum(axis=0)
+    assert np.abs(cs - ref).max() <= 1e-13 * ref.max()
+    # unsupported shapes answer without launching anything
+    assert not lib.regressor_tsqr_fused(robot.device_model(), 0, 1000, d_q, d_v, d_a, d_W, 84, d_cs, d_kept, n, d_tau, -1.0, d_R)
