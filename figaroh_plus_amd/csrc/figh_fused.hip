@@ -222,7 +222,13 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
             FUSED_TICK(c1);
             FUSED_ADD(1, c1 - c0);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+            for (int jo = 0; jo < NJ; ++jo) {
+                // Row order 0, NJ-1, 1, NJ-2, ...: a row block of joint 1 costs a consumer ten times what one of joint 6 costs
+                // (104 against 11 chunk-steps for UR10), and with only one tile of slack per producer the consumers would
+                // all be busy during the heavy half of a sample tile and all be waiting during the light half.
+                const int j = (jo & 1) ? NJ - 1 - (jo >> 1) : (jo >> 1);
+                const int jprev = jo == 0 ? (((NJ - 1) & 1) ? NJ - 1 - ((NJ - 1) >> 1) : ((NJ - 1) >> 1))
+                                          : (((jo - 1) & 1) ? NJ - 1 - ((jo - 1) >> 1) : ((jo - 1) >> 1));
                 FUSED_TICK(c2);
                 // the buffer is free once the previous tile has been gathered by its consumer (this wave's own reads of it
                 // -- stream-out, column norms -- are behind it in program order)
@@ -230,11 +236,12 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
                 asm volatile("" ::: "memory");
                 FUSED_TICK(c3);
                 FUSED_ADD(0, c3 - c2);
-                // ---- this lane's row (j, i): 14 columns per link; links < j are structurally zero, and the columns below
-                // 14 (j - 1) still hold the zeros of the previous row of this sample tile
-                if (j > 0) {
+                // ---- this lane's row (j, i): 14 columns per link; links < j are structurally zero.  The buffer holds the row
+                // of joint jprev (zeros below 14 jprev, values from there on; the kernel's very first tile is row 0, which
+                // writes every column): only [14 jprev, 14 j) has to be cleared
+                if (j > jprev) {
 #pragma unroll
-                    for (int c = 14 * (j - 1); c < 14 * j; ++c) my[c] = 0.0;
+                    for (int c = 14 * jprev; c < 14 * j; c += 2) *reinterpret_cast<f64x2 *>(my + c) = f64x2{0.0, 0.0};
                 }
                 double Jl[3] = {0, 0, 0}, Ja[3] = {opaque_v(P.axis[j][0]), opaque_v(P.axis[j][1]), opaque_v(P.axis[j][2])};
 #pragma unroll
@@ -438,6 +445,19 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
     for (int cc = 0; cc < NCC; ++cc)
 #pragma unroll
         for (int i = 0; i < RPL; ++i) S.T[cc][i] = 0.0;
+    // structure of the joint-torque regressor of a chain (regressor.py:45-87): the row block of joint j has exact zeros in the
+    // columns of the links in front of j -- the producer writes them as such -- so a tile's first kept column that can be
+    // non-zero is known from its row block: fpos[j] = pad + #{kept columns < 14 j}.  Chunks in front of it are not gathered.
+    int fpos[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fpos[j] = pad;
+    for (int e = 0; e < n; ++e) {
+        const int c = col_idx[e];
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) fpos[j] += (c < 14 * j) ? 1 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fpos[j] = __builtin_amdgcn_readfirstlane(fpos[j]);  // (uniform: scalar registers)
     FusedCtrl *ctrl0 = reinterpret_cast<FusedCtrl *>(lds + G::CTRL0);
     FusedCtrl *ctrl1 = reinterpret_cast<FusedCtrl *>(lds + G::PSIZE + G::CTRL0);
 
@@ -483,9 +503,20 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
         FUSED_ADD(8, c1 - c0);
         const double *tile = lds + pick * G::PSIZE;
         FusedCtrl *ctrl = pick ? ctrl1 : ctrl0;
+        // row block of the tile: the producer's row order 0, NJ-1, 1, NJ-2, ...
+        const int jo = tpick % NJ;
+        const int jrow = (jo & 1) ? NJ - 1 - (jo >> 1) : (jo >> 1);
+        int first_nz = fpos[0];
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) first_nz = jrow == j ? fpos[j] : first_nz;
+        first_nz = __builtin_amdgcn_readfirstlane(first_nz);
 #pragma unroll
         for (int cc = 0; cc < NCC; ++cc) {
-            if (wlive[cc]) {
+            // (cleared first: what the previous tile left in the registers is dead, no merge with it)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) S.T[cc][i] = 0.0;
+            // a chunk whose lane-columns all lie in front of first_nz holds structural zeros only (wave-uniform test)
+            if (wlive[cc] && 16 * cc + 15 >= first_nz) {
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) S.T[cc][i] = tile[(16 * (i >> 2) + 4 * (i & 3)) * LDT + loff[cc]];
             }
@@ -498,19 +529,6 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
         lds_post(&ctrl->taken, tpick + 1);
         FUSED_TICK(c2);
         FUSED_ADD(9, c2 - c1);
-
-        // zero-column map of the tile: bit = padded lane-column position with a non-zero entry
-        unsigned long long nzlo = 0;
-#pragma unroll
-        for (int cc = 0; cc < NCC; ++cc) {
-            bool nz = false;
-#pragma unroll
-            for (int i = 0; i < RPL; ++i) nz |= (S.T[cc][i] != 0.0);
-            const unsigned long long bl = __ballot(nz);
-            const unsigned m16 = (unsigned)((bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xffffull);
-            nzlo |= (unsigned long long)m16 << (16 * cc);
-        }
-        const int first_nz = nzlo ? __ffsll((long long)nzlo) - 1 : 16 * NCC;
         tsqr2_panels<0, NCC, NRC, true, true>(S, first_nz, [](auto) {});
         FUSED_TICK(c3);
         FUSED_ADD(10, c3 - c2);

@@ -64,6 +64,8 @@ for o in opts:
                 print("   " + ", ".join("%s %.1f%%" % (names[k], 100.0 * vals[k] / vals[tot])
                                         for k in range(base, tot) if k in names))
         if vals[12] > 0:
+            print("   LDS read round trip (one dependent ds_read_b64 + wait, incl. 2 counter reads): producer %.0f, consumer %.0f "
+                  "ticks" % (vals[6] / vals[12], vals[13] / vals[12]))
             print("   ticks per tile: producer %.0f (x1 wave), consumer busy %.0f; tiles %d" % (
                 vals[5] / vals[12] * reps * 0 + vals[5] / (vals[12]), (vals[9] + vals[10]) / vals[12], vals[12] / reps))
     del pipe
