@@ -171,9 +171,10 @@ def main():
                     help="samples of the CPU baseline legs (default: 300000 for cfg2, 20000 for cfg3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
-    ap.add_argument("--placement-trials", type=int, default=8,
+    ap.add_argument("--placement-trials", type=int, default=1,
                     help="set-up (untimed): candidate allocations of W among which the one K1 writes fastest is kept "
-                         "(IdentificationPipeline.placement_trials; 1 = take the first)")
+                         "(IdentificationPipeline.placement_trials; 1 = take the first, the default since round 4: the fused "
+                         "launch writes W at half the rate the stand-alone regressor kernel needs and does not depend on it)")
     ap.add_argument("--structural-zeros", default="every-pass", choices=["every-pass", "once"],
                     help="once = opt-in variant for the joint-torque regressor of a tree (cfg3): W is zero-filled at set-up "
                          "and the regressor kernel leaves its structural zeros alone (FIGH_FLAG_ZEROS_PRESENT); every entry "
@@ -184,6 +185,12 @@ def main():
                          "in joint-torque mode, cfg3) = row block j as its own N x 16 |subtree_j| matrix: only the window of a "
                          "row that can be non-zero is stored, written and read, every stored byte in every pass "
                          "(FIGH_FLAG_COMPACT_BLOCKS).  auto = block-compact where it applies; config.w_layout says which")
+    ap.add_argument("--no-wls", action="store_true",
+                    help="cfg3: leave the weighted least squares (examples/staubli_TX40/identification.py:305-346) out of the "
+                         "timed step (default: included, as BASELINE configs[2] says \"WLS solve\")")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="cfg2: K1 and the level-0 TSQR as two launches (W written, then read back) instead of the fused "
+                         "launch figh_regressor_tsqr_fused (default: fused from the second pass on; config.fused says which)")
     ap.add_argument("--host-wait", default=None, choices=["spin", "block"],
                     help="how the host waits for the GPU: spin (default for one GPU) or block = interrupt-driven (default "
                          "for several ranks on a node: spinning ranks can exhaust a container's CPU quota)")
@@ -243,7 +250,7 @@ def main():
     pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
                                   chunk_samples=chunk, placement_trials=args.placement_trials,
                                   structural_zeros=args.structural_zeros,
-                                  w_layout="dense" if args.w_layout == "dense" else "block-compact")
+                                  w_layout="dense" if args.w_layout == "dense" else "block-compact", fuse=not args.no_fuse)
     _lib.synchronize()
     t_h2d = time.perf_counter()
     pipe.set_samples(q, v, a)
@@ -251,7 +258,9 @@ def main():
     t_h2d = time.perf_counter() - t_h2d - 1e-3 * getattr(pipe, "repack_ms", 0.0)
     input_bytes = q.nbytes + v.nbytes + a.nbytes
     phi_ref = np.array([float(x) for x in meta["phi_ref_raw"]])
-    pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config == "cfg2" else 0.0, seed=rank)
+    # cfg3 is quoted with a WLS solve (BASELINE configs[2]): measurement noise, or the per-joint variances are round-off
+    pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config in ("cfg2", "cfg3") else 0.0, seed=rank)
+    wls = args.config == "cfg3" and not args.no_wls
     del q, v, a
 
     out = None
@@ -260,14 +269,14 @@ def main():
     # on during warm-up already so that the event pool exists before the timed region
     _lib.profile_enable(True, level=1)
     for _ in range(args.warmup):
-        out = pipe.run()
+        out = pipe.run(wls=wls)
     _lib.profile_reset()
     barrier()
     step_times = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
-        out = pipe.run()  # returns when its results are on the host: the per-step clock needs no extra synchronisation
+        out = pipe.run(wls=wls)  # returns when its results are on the host: the per-step clock needs no extra synchronisation
         step_times.append(time.perf_counter() - ts)
     barrier()
     dt = time.perf_counter() - t0
@@ -297,8 +306,8 @@ def main():
     _lib.profile_enable(True, level=2)
     _lib.profile_reset()
     for _ in range(2):
-        pipe.run()
-    for name in ("tsqr_tree", "tsqr_reduce", "select_columns", "rccl_allgather", "rccl_allreduce"):
+        pipe.run(wls=wls)
+    for name in ("triangle_residuals", "tsqr_tree", "tsqr_reduce", "select_columns", "rccl_allgather", "rccl_allreduce"):
         cnt, ms = _lib.profile_get(name)
         if cnt:
             kern[name] = {"launches_per_step": cnt / 2.0, "avg_ms": ms / cnt, "timed_region": False}
@@ -327,6 +336,30 @@ def main():
         sec = kern[k1_name]["avg_ms"] * 1e-3 * launches_per_step[k1_name]  # (the streamed pass runs K1' twice per chunk)
         roof[k1_name] = {"bound": "hbm", "achieved": bytes_per_sample * N / sec / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_sample": bytes_per_sample}
+    if "fused_chain_tsqr" in kern:
+        # one launch does stage A (the regressor, written to HBM) and stage B level 0 (the TSQR of the kept columns, out of
+        # LDS): its time is bounded from below by max(algorithmic bytes / HBM peak, algorithmic flops / fp64 peak); the
+        # larger of the two bounds is the roof it is measured against, the other one is reported beside it
+        sec = kern["fused_chain_tsqr"]["avg_ms"] * 1e-3 * launches_per_step["fused_chain_tsqr"]
+        gbs = bytes_per_sample * N / sec / 1e9
+        tfs = flops_per_sample * N / sec / 1e12
+        kept = np.array([meta["names_std"].index(p) for p in out["params_r"]])
+        first = np.searchsorted(kept, 14 * np.arange(rows_per_sample))
+        ex_flops = int(sum(2 * (n_kept + 1 - f) ** 2 for f in first))
+        hbm_bound = gbs / HBM_PEAK_GBS >= tfs / FP64_PEAK_TFLOPS
+        roof["fused_chain_tsqr"] = {
+            "bound": "hbm" if hbm_bound else "fp64",
+            "achieved": gbs if hbm_bound else tfs, "peak": HBM_PEAK_GBS if hbm_bound else FP64_PEAK_TFLOPS,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "traffic": None,
+            "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_flops_per_sample": flops_per_sample,
+            "executed_flops_per_sample": ex_flops,
+            "hbm": {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS},
+            "fp64": {"achieved_TFLOPs": tfs, "frac": tfs / FP64_PEAK_TFLOPS, "executed_TFLOPs": ex_flops * N / sec / 1e12,
+                     "pipe": "fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand; no MFMA instruction is issued -- "
+                             "v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak and shares the FP64 datapath)"},
+            "what": "regressor rows produced by two waves per CU into LDS tiles, streamed to W (every byte of the 6N x 84 "
+                    "matrix written in every pass), each tile factored out of LDS by one of six consumer waves: W is not "
+                    "read back"}
     if "tsqr" in kern:
         sec = kern["tsqr"]["avg_ms"] * 1e-3 * launches_per_step["tsqr"]
         roof["tsqr"] = {"bound": "fp64", "achieved": flops_per_sample * N / sec / 1e12, "peak": FP64_PEAK_TFLOPS,
@@ -370,13 +403,13 @@ def main():
     # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
     # tools/pmc_summary.py), i.e. from the builder's run, not from this one
     try:
-        pmc_file = next(n for n in ("r03_pmc_summary.json", "r02_pmc_summary.json")
+        pmc_file = next(n for n in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
                         if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
         if args.config == "cfg2" and N == 1_000_000:
             for key, kname in (("regressor_chain", "regressor_chain_kernel<6, false, true>"),
-                               ("tsqr", "tsqr2_kernel<4, 4, true>")):
+                               ("tsqr", "tsqr2_kernel<4, 4, true>"), ("fused_chain_tsqr", "fused_chain_tsqr_kernel<6>")):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
                     roof[key]["traffic_source"] = ("profiles/%s: a committed rocprofv3 --pmc run of this command, NOT "
@@ -425,7 +458,10 @@ def main():
                     "cfg2": "BASELINE configs[1]: UR10 6-DoF, %d synthetic (q,qd,qdd) samples per GPU, full inertial "
                             "regressor materialised (6N x 84) + elimination + Householder TSQR base params + LS" % N,
                     "cfg3": "BASELINE configs[2]: TIAGo, fv/fs + actuator inertia + offset columns, %d samples in total, "
-                            "regressor (24N x 336, device-resident, link-padded) + elimination + blocked TSQR + LS" % n_total,
+                            "regressor (24N x 336, device-resident, link-padded) + elimination + blocked TSQR + LS%s" % (
+                                n_total, " + WLS solve (per-joint variances from the OLS residuals, weighted factorisation "
+                                "of the per-row-block triangles: %s)" % out.get("wls_source", "") if wls else
+                                " (WLS left out: --no-wls)"),
                     "cfg4": "BASELINE configs[3]: TALOS floating base, external-wrench regressor, %d samples in total "
                             "sharded over the GPUs, regressor (6N x 462, device-resident, link-padded) + blocked TSQR" % n_total,
                     "cfg5": "BASELINE configs[4]: human whole-body, %d samples in total sharded over the GPUs, streamed in "
@@ -441,6 +477,9 @@ def main():
                              % (8e-9 * pipe.N * float(pipe._compact[1].sum()), 8e-9 * pipe.W.rows * pipe.W.ld))
                 if getattr(pipe, "_compact", None) is not None else "dense",
                 "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
+                "fused": ("K1 + level-0 TSQR in one launch (figh_regressor_tsqr_fused), %d of the %d timed and warm-up passes"
+                          % (pipe.fused_passes, args.steps + args.warmup + 2)) if pipe.fused_passes else
+                         "no (two launches: W written by K1, read back by the TSQR)",
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
             "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},

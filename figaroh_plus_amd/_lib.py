@@ -72,7 +72,8 @@ SIGNATURES = {
                                             C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected_blocks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+                                            C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "figh_block_triangle_residuals": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_regressor_tsqr_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -427,10 +428,11 @@ def tsqr_selected_wrench(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_e
 
 
 def tsqr_selected_blocks(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_expected, counts, d_cols, d_pos, d_tau,
-                         tol_qr, d_sel, d_R, block_off=None, block_ld=None):
+                         tol_qr, d_sel, d_R, block_off=None, block_ld=None, d_block_tri=None):
     """tsqr_selected with one column list per row block (joint-torque regressor of a tree, figh.h); ``counts``: int32
     host array, one entry per row block; ``block_off`` / ``block_ld``: the block-compact W (element offsets, int64, and
-    leading dimensions, int32, per row block)."""
+    leading dimensions, int32, per row block); ``d_block_tri`` ((nblocks + 1) nc^2 doubles, optional) receives the embedded
+    per-row-block triangles."""
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     off = ld = None
     if block_off is not None:
@@ -440,7 +442,13 @@ def tsqr_selected_blocks(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_e
                                            len(counts), counts.ctypes.data, d_cols.ptr, d_pos.ptr,
                                            off.ctypes.data if off is not None else None,
                                            ld.ctypes.data if ld is not None else None,
-                                           d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr, d_R.ptr))
+                                           d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr, d_R.ptr,
+                                           d_block_tri.ptr if d_block_tri is not None else None))
+
+
+def block_triangle_residuals(d_tri, count, nc, d_v, d_r2):
+    """d_r2[b] = || R_b v ||^2 over ``count`` stacked nc x nc triangles (figh.h)."""
+    check(load().figh_block_triangle_residuals(d_tri.ptr, count, nc, d_v.ptr, d_r2.ptr))
 
 
 def regressor_tsqr_fused(model, flags, N, d_q, d_v, d_a, d_W, ldw, d_colsq, d_kept, n, d_tau, tol_qr, d_R):

@@ -1128,7 +1128,7 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
 int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nblocks, const int32_t *h_counts, const int32_t *d_cols,
                               const int32_t *d_pos, const int64_t *h_block_off, const int32_t *h_block_ld,
-                              const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out) {
+                              const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out, double *d_block_tri) {
     FIGH_REQUIRE(d_W && d_colsq && d_sel && d_R_out && h_counts && d_cols && d_pos, "NULL pointer");
     FIGH_REQUIRE((h_block_off == nullptr) == (h_block_ld == nullptr), "block offsets and leading dimensions come together");
     FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
@@ -1150,7 +1150,9 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         nmax = std::max(nmax, h_counts[j] + (d_tau ? 1 : 0));
     }
     const size_t tri = sizeof(double) * (size_t)nc * nc;
-    double *stack = static_cast<double *>(workspace(tri * (size_t)(nblocks + 1), 26));
+    // the embedded per-row-block triangles: the caller's buffer when it wants to keep them (weighted solve afterwards:
+    // figh_block_triangle_residuals + figh_tsqr over the stack with row-block weights), else a library workspace
+    double *stack = d_block_tri ? d_block_tri : static_cast<double *>(workspace(tri * (size_t)(nblocks + 1), 26));
     const int64_t cap_b = std::max(figh_tsqr_level0_capacity(nmax), figh_tsqr_level0_capacity(std::min(nmax, 80)));
     double *tri_b = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax * cap_b, 23));
     double *Rb = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax, 24));
@@ -1164,7 +1166,13 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         const double *tj = d_tau ? d_tau + (int64_t)j * rows_b : nullptr;
         if (nj == 0) {  // (only tau in this block: its norm still counts)
             off += nj;
-            if (!d_tau) continue;
+            if (!d_tau) {
+                if (d_block_tri) {  // (kept stacks have one slot per row block: an empty one is a zero triangle)
+                    FIGH_HIP(hipMemsetAsync(stack + (size_t)have * nc * nc, 0, tri, stream()));
+                    ++have;
+                }
+                continue;
+            }
         }
         int64_t cnt = 0;
         if (nj > 0) {
@@ -1185,6 +1193,37 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         have = 1;
     }
     return tsqr_reduce_stack(stack, have, nc, n, tol_qr, d_R_out);
+}
+
+// r2[b] = || R_b v ||^2 for `count` stacked nc x nc upper triangles: one workgroup per triangle, rows over the threads,
+// fixed-order tree (deterministic)
+__global__ __launch_bounds__(256) void triangle_residuals_kernel(const double *__restrict__ Rs, const int nc,
+                                                                 const double *__restrict__ v, double *__restrict__ r2) {
+    __shared__ double sm[256];
+    const double *R = Rs + (size_t)blockIdx.x * nc * nc;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nc; k += 256) {
+        double d = 0.0;
+        for (int c = k; c < nc; ++c) d += R[(size_t)k * nc + c] * v[c];
+        s += d * d;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) r2[blockIdx.x] = sm[0];
+}
+
+int figh_block_triangle_residuals(const double *d_tri, int count, int nc, const double *d_v, double *d_r2) {
+    FIGH_REQUIRE(d_tri && d_v && d_r2, "NULL device pointer");
+    FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 1024, "bad shape");
+    if (int rc = ensure_device()) return rc;
+    ProfileScope scope("triangle_residuals");
+    hipLaunchKernelGGL(triangle_residuals_kernel, dim3((unsigned)count), dim3(256), 0, stream(), d_tri, nc, d_v, d_r2);
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
 }
 
 int figh_tsqr_merge_base(const double *d_Rs, int count, int nc, int n_free, double tol_qr, double *d_Rk_out) {

@@ -261,14 +261,26 @@ class IdentificationPipeline:
         d_stack, count = ex.stack_triangles(d_R, nc)
         return self._tail(d_stack, count, n, nc, params_r, idx_e, col_norm, with_tau, rps * self.N * ex.world_size, strings)
 
-    def run(self, strings=True):
-        """One pass.  Nothing returns to the host before the end: K1 leaves diag(W^T W) in HBM, the kept-column list is
+    def run(self, strings=True, wls=False):
+        """One pass.  ``wls=True`` appends the weighted least squares of the example scripts
+        (examples/staubli_TX40/identification.py:305-346: per-joint variances from the OLS residuals, rows scaled by
+        1 / sigma_j) on the data that is already in HBM: ``phi_wls``, ``std_wls`` (%), ``sigma2_joint``.
+
+        One pass.  Nothing returns to the host before the end: K1 leaves diag(W^T W) in HBM, the kept-column list is
         formed there (figh_tsqr_selected), the TSQR is launched with the column COUNT of the previous pass, the merge tree
         ends in the rank-revealing level, and one copy brings back [column norms | selection | triangle rows].  The count
         is verified against the device's own afterwards; the first pass (count unknown) and a pass whose count changed
         repeat the solve with the right one."""
         if self._chunked():
+            if wls:
+                raise NotImplementedError("wls=True needs the regressor resident in HBM (no chunk_samples)")
             return self._run_chunked(strings)
+        out = self._run_resident(strings, wls)
+        if wls:
+            self._wls(out)
+        return out
+
+    def _run_resident(self, strings, wls):
         ex = self.exchange
         # K1 (+ fused column norms)
         mode, flags, ft_mask = self._flags()
@@ -367,10 +379,11 @@ class IdentificationPipeline:
                 _lib.tsqr_selected_blocks(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, blocks[1],
                                           blocks[4] if coff is not None else blocks[2], blocks[3], self.d_tau,
                                           self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R,
-                                          block_off=coff, block_ld=cld)
+                                          block_off=coff, block_ld=cld, d_block_tri=self._block_tri(wls, len(blocks[1]), nc))
             else:
                 _lib.tsqr_selected(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, self._hint_blocks, n, self.d_tau,
                                    self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
+            self._have_block_tri = bool(wls and blocks is not None and not split)
             if not local:
                 if n > 0:
                     d_stack, count = ex.stack_triangles(self._d_R, nc)
@@ -419,6 +432,7 @@ class IdentificationPipeline:
         (figh_regressor_tsqr_fused).  Returns None -- the caller takes the two-launch path -- when the shape is not supported
         or the kept set turned out to be different."""
         ex, lib, W = self.exchange, _lib.load(), self.W
+        self._have_block_tri = False
         mask, d_kept, n = self._fused_kept
         ncols, with_tau = W.ref_cols, self.d_tau is not None
         nc = n + (1 if with_tau else 0)
@@ -455,6 +469,80 @@ class IdentificationPipeline:
             self._kept_cache = (mask.copy(), list(idx_e), list(params_r))
         rows_k = host[ncols + self._sel_words:].reshape(nc + 1, nc)
         return self._finish(rows_k, n, nc, params_r, idx_e, host[:ncols].copy(), with_tau, W.rows * ex.world_size, strings)
+
+    def _block_tri(self, wls, nblocks, nc):
+        """Device buffer for the per-row-block triangles of figh_tsqr_selected_blocks (kept for the weighted solve)."""
+        if not wls:
+            return None
+        need = (nblocks + 1) * nc * nc
+        buf = getattr(self, "_d_block_tri", None)
+        if buf is None or buf.size < need:
+            buf = self._d_block_tri = _lib.DeviceArray((need,), np.float64)
+        return buf
+
+    def _wls(self, out):
+        """Weighted least squares of examples/staubli_TX40/identification.py:305-346 (what
+        identification_tools.weighted_least_squares_blocks does on a host W_b), device-resident:
+        sigma_j^2 = ||tau_j - W_b,j phi_b||^2 / n_j per joint row block, phi = (W^T S^-1 W)^-1 W^T S^-1 tau, rounded to 6
+        decimals, C_X = (W^T S^-1 W)^-1, std% = 100 sqrt(diag C_X) / |phi| (2 decimals).  phi_b is the rounded OLS solution
+        of the pass, as in the script.
+
+        Tree models whose pass went through per-row-block triangles (TIAGo): both the residual norms and the weighted
+        triangle come from those nblocks small triangles -- W is not read again.  Otherwise: one pass over W for the
+        residuals (figh_matvec + figh_block_sqnorm) and one weighted TSQR over the base columns (figh_tsqr with row-block
+        weights), straight from the resident W in whatever layout it has."""
+        if self.d_tau is None:
+            raise ValueError("wls=True needs tau")
+        ex, W = self.exchange, self.W
+        n = len(out["params_r"])
+        nc = n + 1
+        base = np.asarray(out["idx_base"], dtype=np.int64)
+        nb_par = len(base)
+        phi_b = np.ascontiguousarray(out["phi_b"], dtype=np.float64)
+        mode, _, _ = self._flags()
+        nblocks = self.robot.model.nv if mode == _lib.MODE_JOINT_TORQUE else 6
+        rows_blk = W.rows // nblocks
+        d_r2 = _lib.DeviceArray((nblocks,), np.float64)
+        d_Rw = _lib.DeviceArray(((nb_par + 1) * (nb_par + 1),), np.float64)
+        kept = np.flatnonzero(self._kept_cache[0])
+        if getattr(self, "_have_block_tri", False):
+            tri = self._d_block_tri
+            v = np.zeros(nc)
+            v[base] = phi_b
+            v[n] = -1.0
+            _lib.block_triangle_residuals(tri, nblocks, nc, _lib.DeviceArray.from_host(v), d_r2)
+            r2 = ex.sum_columns(d_r2, nblocks)
+            sig2 = r2 / (rows_blk * ex.world_size)
+            d_cols = _lib.DeviceArray.from_host(np.r_[base, n].astype(np.int32))
+            _lib.tsqr(tri, nblocks * nc, nc, d_cols, nb_par + 1, None, 1.0 / np.sqrt(sig2), d_Rw)
+            source = "per-row-block triangles"
+        else:
+            if self._compact is not None:
+                raise RuntimeError("block-compact W without per-row-block triangles")
+            d_cols = _lib.DeviceArray.from_host(np.asarray(self.device_columns(kept[base]), dtype=np.int32))
+            d_est = _lib.DeviceArray((W.rows,), np.float64)
+            _lib.matvec(W.buf, W.rows, W.ld, d_cols, nb_par, _lib.DeviceArray.from_host(phi_b), d_est)
+            _lib.block_sqnorm(self.d_tau, d_est, W.rows, nblocks, d_r2)
+            d_est.free()
+            r2 = ex.sum_columns(d_r2, nblocks)
+            sig2 = r2 / (rows_blk * ex.world_size)
+            _lib.tsqr(W.buf, W.rows, W.ld, d_cols, nb_par, self.d_tau, 1.0 / np.sqrt(sig2), d_Rw)
+            source = "second pass over W"
+        if getattr(ex, "collective", True) and ex.world_size > 1:
+            d_stack, count = ex.stack_triangles(d_Rw, nb_par + 1)
+            d_one = _lib.DeviceArray(((nb_par + 1) * (nb_par + 1),), np.float64)
+            _lib.tsqr_merge(d_stack, count, nb_par + 1, d_one)
+            d_Rw = d_one
+        Rw = d_Rw.to_host().reshape(nb_par + 1, nb_par + 1)
+        R, z = np.triu(Rw[:nb_par, :nb_par]), Rw[:nb_par, nb_par]
+        with _single_threaded_blas(nb_par):
+            phi = np.around(_solve_upper(np.asfortranarray(R), np.asfortranarray(z.reshape(-1, 1)))[:, 0], 6)
+            R_inv, info = _dtrtri(np.ascontiguousarray(R))
+            if info != 0:
+                raise np.linalg.LinAlgError("Singular matrix")
+            std = np.round(100 * np.sqrt(np.einsum("ij,ij->i", R_inv, R_inv)) / np.abs(phi), 2)
+        out["phi_wls"], out["std_wls"], out["sigma2_joint"], out["wls_source"] = phi, std, sig2, source
+        return out
 
     def _block_lists(self, ncols, stride):
         """(mask, counts, d_cols, d_pos) for figh_tsqr_selected_blocks, from the kept mask this pass expects: row block j
