@@ -35,6 +35,42 @@ def get_param_from_yaml(robot, identif_data):
     return param
 
 
+def set_missing_params_setting(robot, params_settings):
+    """Defaults for what the URDF does not specify (identification_tools.py:86-165), statement for statement -- including
+    the reference's own slips, which a drop-in keeps: ``diff_limit.any`` is never called (so the position limits are
+    never replaced), the effort-limit branch tests the VELOCITY limits again and writes ``-tau_lim_def``, and the loops
+    run over ``nq``.  Side effects on ``robot.model`` as in the reference; returns the updated ``params_settings``
+    (``accelerationLimit``, ``fv`` / ``fs`` = (i + 1) / 10 with friction, ``OFFX`` / ``OFFY`` / ``OFFZ`` = 900 / 450 / 0
+    with external-wrench offsets)."""
+    model = robot.model
+    diff_limit = np.setdiff1d(model.lowerPositionLimit, model.upperPositionLimit)
+    if not diff_limit.any:  # (a bound method: always true, as in the reference)
+        print("No joint limits. Set default values")
+        for ii in range(model.nq):
+            model.lowerPositionLimit[ii] = -params_settings["q_lim_def"]
+            model.upperPositionLimit[ii] = params_settings["q_lim_def"]
+    if np.sum(model.velocityLimit) == 0:
+        print("No velocity limit. Set default value")
+        for ii in range(model.nq):
+            model.velocityLimit[ii] = params_settings["dq_lim_def"]
+    if np.sum(model.velocityLimit) == 0:
+        print("No joint torque limit. Set default value")
+        for ii in range(model.nq):
+            model.effortLimit[ii] = -params_settings["tau_lim_def"]
+    accelerationLimit = np.zeros(model.nq)
+    for ii in range(model.nq):
+        accelerationLimit[ii] = params_settings["ddq_lim_def"]
+    params_settings["accelerationLimit"] = accelerationLimit
+    if params_settings["has_friction"]:
+        params_settings["fv"] = [(ii + 1) / 10 for ii in range(model.nv)]
+        params_settings["fs"] = [(ii + 1) / 10 for ii in range(model.nv)]
+    if params_settings["external_wrench_offsets"]:
+        params_settings["OFFX"] = 900
+        params_settings["OFFY"] = 450
+        params_settings["OFFZ"] = 0
+    return params_settings
+
+
 def base_param_from_standard(phi_standard, params_base):
     """Evaluate the regrouping expressions on standard-parameter values (identification_tools.py:168-201)."""
     ops = {"+": operator.add, "-": operator.sub}

@@ -251,3 +251,30 @@ def test_calibration_parameter_names():
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "calibration_base_regressor.json")))
     assert set(ref["tx40_full"]["paramsrand_e"]) <= set(geo)
     assert set(ref["talos_offsets"]["paramsrand_e"]) <= set(off)
+
+
+def test_set_missing_params_setting_matches_reference():
+    """identification_tools.py:86-165 against what the reference's own function returns, prints and does to the model
+    (tests/golden/missing_params.json, oracle/gen_golden_missing_params.py)."""
+    import contextlib
+    import io
+    import json
+    import os
+    import types
+    from figaroh_plus_amd.identification.identification_tools import set_missing_params_setting
+    with open(os.path.join(os.path.dirname(__file__), "golden", "missing_params.json")) as f:
+        fixtures = json.load(f)
+    for name, fx in fixtures.items():
+        c = fx["input"]
+        model = types.SimpleNamespace(lowerPositionLimit=np.array(c["lower"]), upperPositionLimit=np.array(c["upper"]),
+                                      velocityLimit=np.array(c["velocity"]), effortLimit=np.array(c["effort"]),
+                                      nq=c["nq"], nv=c["nv"])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            res = set_missing_params_setting(types.SimpleNamespace(model=model), dict(c["settings"]))
+        assert buf.getvalue() == fx["printed"], name
+        got = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in res.items()}
+        assert got == fx["result"], name
+        after = fx["model_after"]
+        assert model.lowerPositionLimit.tolist() == after["lower"] and model.upperPositionLimit.tolist() == after["upper"]
+        assert model.velocityLimit.tolist() == after["velocity"] and model.effortLimit.tolist() == after["effort"]
