@@ -80,6 +80,8 @@ SIGNATURES = {
                                             C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double,
                                             C.c_void_p]),
     "figh_tsqr_merge_base": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
+    "figh_compact_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                                    C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "figh_base_permutation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "figh_regressor_colsq": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
@@ -395,6 +397,14 @@ def filtfilt_cols(d_X, rows, cols, ldx, nblocks, form, b, a, zi, padlen, q, d_Y,
     check(load().figh_filtfilt_cols(d_X.ptr, rows, cols, ldx, nblocks, form, b.ctypes.data_as(_c_double_p),
                                     a.ctypes.data_as(_c_double_p), nsec, order, zi.ctypes.data_as(_c_double_p), padlen, q,
                                     d_Y.ptr, ldy, C.byref(out)))
+    return out.value
+
+
+def compact_rows(W_ptr, rows, cols, ldw, tau_ptr, key_col, threshold, Wout_ptr, ld_out, tauout_ptr):
+    """figh_compact_rows on raw device addresses (views into larger buffers); returns the number of kept rows."""
+    out = C.c_int64(0)
+    check(load().figh_compact_rows(W_ptr, rows, cols, ldw, tau_ptr, key_col, threshold, Wout_ptr, ld_out, tauout_ptr,
+                                   C.byref(out)))
     return out.value
 
 

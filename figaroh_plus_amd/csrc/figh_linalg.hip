@@ -584,6 +584,65 @@ __global__ __launch_bounds__(256) void scatter_regrouped_kernel(const double *__
     }
 }
 
+// Row rejection of the real-data scripts (examples/staubli_TX40/identification.py:207-233, examples/tiago/identification.py
+// :170-187: rows whose joint velocity -- the fv column of the joint's own link -- is below a threshold are dropped from W
+// and tau), as an order-preserving stream compaction.  Pass 1: kept rows per 64-row group; pass 2: exclusive scan of the
+// group counts (one workgroup); pass 3: every wave copies the kept rows of its group to their final place, lanes across
+// the columns.
+__global__ __launch_bounds__(256) void compact_count_kernel(const double *__restrict__ W, const long rows, const long ldw,
+                                                            const int key_col, const double thr, int *__restrict__ cnt) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = r < rows && fabs(W[r * ldw + key_col]) >= thr;
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) cnt[r >> 6] = __popcll(m);
+}
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int *__restrict__ cnt, const long ngroups, long *__restrict__ total) {
+    __shared__ long part[1024];
+    const long per = (ngroups + 1023) / 1024;
+    const long lo = threadIdx.x * per, hi = lo + per < ngroups ? lo + per : ngroups;
+    long s = 0;
+    for (long i = lo; i < hi; ++i) s += cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    long run = part[threadIdx.x];
+    for (long i = lo; i < hi; ++i) {
+        const int v = cnt[i];
+        cnt[i] = (int)run;  // (exclusive offsets; the host side bounds rows below 2^31)
+        run += v;
+    }
+}
+__global__ __launch_bounds__(256) void compact_copy_kernel(const double *__restrict__ W, const long rows, const int cols,
+                                                           const long ldw, const double *__restrict__ tau, const int key_col,
+                                                           const double thr, const int *__restrict__ off,
+                                                           double *__restrict__ Wo, const long ldo, double *__restrict__ tauo) {
+    const int lane = threadIdx.x & 63;
+    const long grp = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long r = grp * 64 + lane;
+    if (grp * 64 >= rows) return;
+    const bool keep = r < rows && fabs(W[r * ldw + key_col]) >= thr;
+    unsigned long long m = __ballot(keep);
+    long dst = off[grp];
+    if (keep && tau) tauo[dst + __popcll(m & ((1ull << lane) - 1ull))] = tau[r];
+    while (m) {  // wave-uniform loop over the kept rows of the group: lanes across the columns
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const double *in = W + (grp * 64 + src) * ldw;
+        double *out = Wo + dst * ldo;
+        for (int c = lane; c < cols; c += 64) out[c] = in[c];
+        ++dst;
+    }
+}
+
 static int cu_count() {
     static int cus = 0;
     if (!cus) {
@@ -780,6 +839,34 @@ int figh_place_block(const double *d_src, int64_t ld_src, int64_t rows, int64_t 
     hipLaunchKernelGGL(place_block_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_src, (long)ld_src, (long)rows,
                        (long)cols, scale, d_dst, (long)ld_dst);
     FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int figh_compact_rows(const double *d_W, int64_t rows, int cols, int64_t ldw, const double *d_tau, int key_col,
+                      double threshold, double *d_W_out, int64_t ld_out, double *d_tau_out, int64_t *h_count_out) {
+    FIGH_REQUIRE(d_W && d_W_out && h_count_out, "NULL pointer");
+    FIGH_REQUIRE((d_tau == nullptr) == (d_tau_out == nullptr), "tau in and out come together");
+    FIGH_REQUIRE(rows >= 0 && rows < (1L << 31) && cols >= 1 && ldw >= cols && ld_out >= cols && key_col >= 0 && key_col < cols,
+                 "bad shape");
+    if (int rc = ensure_device()) return rc;
+    *h_count_out = 0;
+    if (rows == 0) return FIGH_OK;
+    const long ngroups = (rows + 63) / 64;
+    int *cnt = static_cast<int *>(workspace(sizeof(int) * (size_t)ngroups + 16, 27));
+    long *total = static_cast<long *>(workspace(sizeof(long), 28));
+    if (!cnt || !total) return FIGH_ERR_ALLOC;
+    ProfileScope scope("compact_rows");
+    const unsigned grid = (unsigned)((rows + 255) / 256);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(grid), dim3(256), 0, stream(), d_W, (long)rows, (long)ldw, key_col, threshold,
+                       cnt);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream(), cnt, ngroups, total);
+    hipLaunchKernelGGL(compact_copy_kernel, dim3(grid), dim3(256), 0, stream(), d_W, (long)rows, cols, (long)ldw, d_tau, key_col,
+                       threshold, cnt, d_W_out, (long)ld_out, d_tau_out);
+    FIGH_HIP(hipGetLastError());
+    long h = 0;
+    FIGH_HIP(hipMemcpyAsync(&h, total, sizeof(long), hipMemcpyDeviceToHost, stream()));
+    FIGH_HIP(hipStreamSynchronize(stream()));
+    *h_count_out = h;
     return FIGH_OK;
 }
 

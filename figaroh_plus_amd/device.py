@@ -71,7 +71,7 @@ def to_device(W):
 
 
 def vector_to_device(x):
-    if isinstance(x, _lib.DeviceArray):
+    if isinstance(x, _lib.DeviceArray) or hasattr(x, "ptr"):  # (device buffers and views of them pass through)
         return x
     return _lib.DeviceArray.from_host(np.ascontiguousarray(x, dtype=np.float64).reshape(-1))
 

@@ -11,7 +11,7 @@ import numpy as np
 
 from .. import _lib
 from .._host import host_tail
-from ..device import to_device, vector_to_device
+from ..device import GpuMatrix, to_device, vector_to_device
 from ..tools.qrdecomposition import rfactor
 
 
@@ -188,7 +188,7 @@ def weigthed_least_squares(robot, phi_b, W_b, tau_meas, tau_est, param):
 
 
 @host_tail
-def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks):
+def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks, return_details=False):
     """Script WLS of examples/staubli_TX40/identification.py:305-346.  ``nblocks``: number of equal joint blocks or
     the list of block lengths.  sigma_j^2 = ||tau_j - W_j phi_b||^2 / n_j, phi = (W^T S^-1 W)^-1 W^T S^-1 tau
     (6 decimals), C_X = (W^T S^-1 W)^-1, std% = 100 sqrt(diag C_X) / |phi| (2 decimals).  Returns (phi, std%)."""
@@ -203,11 +203,20 @@ def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks):
     else:
         counts = np.asarray(nblocks, dtype=np.int64)
         weights = np.repeat(1.0 / np.sqrt(sq / counts), counts)  # one weight per row
-    R, z, _ = _triangle_with_tau(Wd, tau, block_weight=weights)
+    R, z, _rho = _triangle_with_tau(Wd, tau, block_weight=weights)
     phi = np.around(np.linalg.solve(R, z), 6)
     R_inv = np.linalg.inv(R)
     C_X = R_inv @ R_inv.T
     std = np.round(100 * np.sqrt(np.diag(C_X)) / np.abs(phi), 2)
+    if return_details:  # the per-joint variances and the weighted triangle of [W_b tau]: what essential_parameters takes
+        if np.isscalar(nblocks):
+            sig2_joint = sq / (Wd.rows // int(nblocks))
+        else:
+            sig2_joint = sq / np.asarray(nblocks, dtype=np.float64)
+        k = R.shape[0]
+        Raug = np.zeros((k + 1, k + 1))
+        Raug[:k, :k], Raug[:k, k], Raug[k, k] = R, z, _rho
+        return phi, std, {"sigma2_joint": sig2_joint, "R_wls": Raug}
     return phi, std
 
 
@@ -331,13 +340,143 @@ def _decimate_design(q, n=8):
     return sos, signal.sosfilt_zi(sos), 3 * ntaps
 
 
+class _DevView:
+    """A window into a device buffer (no ownership; keeps its base alive)."""
+
+    def __init__(self, base, byte_offset):
+        self.base = base
+        self.ptr = base.ptr + int(byte_offset)
+
+
+def _decimate_device(W, tau, nblocks, q, stages):
+    """decimate_joint_blocks for a regressor that lives in HBM: the stages run device buffer to device buffer
+    (figh_filtfilt_cols), the blocks come back as GpuMatrix / device-vector views of one stacked result."""
+    sos, zi, padlen = _decimate_design(q)
+    d_tau = vector_to_device(tau)
+    ntau = getattr(d_tau, "size", None) or len(tau)
+    nj = ntau // nblocks
+    if W.rows < nblocks * nj:
+        raise ValueError("device-resident decimation needs W to cover the %d joint blocks of tau" % nblocks)
+
+    def run(buf, rows, cols, ld):
+        for _ in range(stages):
+            L = rows // nblocks
+            if L <= padlen:
+                raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % padlen)
+            rows_out = ((L + q - 1) // q) * nblocks
+            d_y = _lib.DeviceArray((rows_out * cols,), np.float64)
+            got = _lib.filtfilt_cols(buf, rows, cols, ld, nblocks, 0, sos[:, :3], sos[:, 3:], zi, padlen, q, d_y, cols)
+            assert got == rows_out
+            buf, rows, ld = d_y, rows_out, cols
+        return buf, rows
+
+    t_buf, t_rows = run(d_tau, nblocks * nj, 1, 1)
+    w_buf, w_rows = run(W.buf, nblocks * nj, W.cols, W.ld)
+    lt, lw = t_rows // nblocks, w_rows // nblocks
+    W_list = [GpuMatrix(_DevView(w_buf, 8 * i * lw * W.cols), lw, W.cols) for i in range(nblocks)]
+    tau_list = [_DevView(t_buf, 8 * i * lt) for i in range(nblocks)]
+    for t in tau_list:
+        t.size = lt
+    return W_list, tau_list
+
+
+def reject_rows(W_list, tau_list, key_cols, thresholds):
+    """Zero-velocity row rejection of the real-data scripts (examples/staubli_TX40/identification.py:207-233,
+    examples/tiago/identification.py:170-187): from joint block i the rows with ``|W_i[:, key_cols[i]]| < thresholds[i]``
+    are dropped (W and tau alike), the surviving blocks are stacked.  Returns (W_, tau_, counts).
+
+    GpuMatrix blocks (decimate_joint_blocks on a device-resident W) are compacted on the device
+    (figh_compact_rows: order-preserving stream compaction) into one GpuMatrix / device vector -- nothing but the six
+    counts returns to the host; NumPy blocks are filtered with NumPy, as in the scripts."""
+    nb = len(W_list)
+    if not (len(tau_list) == len(key_cols) == len(thresholds) == nb):
+        raise ValueError("one key column and one threshold per joint block")
+    if not isinstance(W_list[0], GpuMatrix):
+        Wk, tk, counts = [], [], []
+        for i in range(nb):
+            keep = np.abs(np.asarray(W_list[i])[:, key_cols[i]]) >= thresholds[i]
+            Wk.append(np.asarray(W_list[i])[keep])
+            tk.append(np.asarray(tau_list[i])[keep])
+            counts.append(int(keep.sum()))
+        return np.vstack(Wk), np.concatenate(tk), counts
+    cols = W_list[0].cols
+    total = sum(w.rows for w in W_list)
+    out = GpuMatrix.empty(total, cols)
+    d_tau = _lib.DeviceArray((max(total, 1),), np.float64)
+    counts, at = [], 0
+    for i in range(nb):
+        w = W_list[i]
+        kept = _lib.compact_rows(w.ptr, w.rows, cols, w.ld, tau_list[i].ptr, int(key_cols[i]), float(thresholds[i]),
+                                 out.ptr + 8 * at * cols, cols, d_tau.ptr + 8 * at)
+        counts.append(int(kept))
+        at += int(kept)
+    out.rows = at
+    d_tau.size, d_tau.shape = at, (at,)
+    d_tau.nbytes = 8 * at
+    return out, d_tau, counts
+
+
+def essential_parameters(R_ols, R_wls, params_base, std_xr, ratio_essential, rows_total=None):
+    """The essential-parameter loop of examples/staubli_TX40/identification.py:354-399 on the two small triangles a pass
+    leaves behind instead of on W: ``R_ols`` = the (r + 1) x (r + 1) R factor of [W_b tau], ``R_wls`` = that of
+    [S^-1/2 W_b, S^-1/2 tau] with the per-joint variances of the full-base WLS (the script keeps using THOSE variances
+    inside the loop: ``diag_SIGMA_e`` is filled from ``sig_ro_joint``, not from ``sig_ro_joint_e``).  Deleting a column of W_b
+    deletes the same column of both triangles, and every quantity of an iteration -- lstsq, relative_stdev, C_X, the WLS
+    solution -- follows from the re-triangularised r x r remainder: the rows of W are never read again.
+
+    While ``max(std) >= ratio_essential * min(std)``: drop the parameter with the largest std% (``np.isclose`` match, as in
+    the script: more than one match raises ValueError like the script's tuple unpacking), OLS (6 decimals) + its std%,
+    WLS (6 decimals) + its std%.  ``rows_total`` = len(tau_) (the row count relative_stdev divides by; without it
+    std_e_ols is left out).  Returns a dict: params_essential, idx_essential (positions in params_base), phi_e_ols,
+    std_e_ols, phi_e_wls, std_e_wls, iterations."""
+    R_ols = np.triu(np.asarray(R_ols, dtype=np.float64))
+    R_wls = np.triu(np.asarray(R_wls, dtype=np.float64))
+    r = R_ols.shape[0] - 1
+    if R_wls.shape != R_ols.shape or len(params_base) != r or len(std_xr) != r:
+        raise ValueError("essential_parameters: triangles, names and std% must describe the same %d parameters" % r)
+    keep = list(range(r))
+    names = list(params_base)
+    std_e = np.asarray(std_xr, dtype=np.float64).copy()
+    out = {"phi_e_ols": None, "std_e_ols": None, "phi_e_wls": None, "std_e_wls": None}
+    it = 0
+    while not (std_e.max() < ratio_essential * std_e.min()):
+        (i,) = np.where(np.isclose(std_e, std_e.max()))
+        del names[int(i[0])]
+        del keep[int(i[0])]
+        k = len(keep)
+
+        def sub(R):  # R factor of the remaining columns [+ tau]
+            return np.linalg.qr(R[:, keep + [r]], mode="r")
+        Ro, Rw = sub(R_ols), sub(R_wls)
+        phi_o = np.around(np.linalg.solve(Ro[:k, :k], Ro[:k, k]), 6)
+        out["phi_e_ols"] = phi_o
+        if rows_total is not None:  # relative_stdev (identification_tools.py:204-234) of (W_essential, phi_e_ols, tau_)
+            res2 = float(np.sum((Ro[:k, :k] @ phi_o - Ro[:k, k]) ** 2) + (Ro[k, k] ** 2 if Ro.shape[0] > k else 0.0))
+            Ri = np.linalg.inv(Ro[:k, :k])
+            C = res2 / (rows_total - k) * (Ri @ Ri.T)
+            out["std_e_ols"] = np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi_o), 2)
+        Rwi = np.linalg.inv(Rw[:k, :k])
+        phi_w = np.around(np.linalg.solve(Rw[:k, :k], Rw[:k, k]), 6)
+        std_e = np.round(100 * np.sqrt(np.einsum("ij,ij->i", Rwi, Rwi)) / np.abs(phi_w), 2)
+        out["phi_e_wls"], out["std_e_wls"] = phi_w, std_e.copy()
+        it += 1
+    out.update(params_essential=names, idx_essential=keep, iterations=it)
+    return out
+
+
+
 def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
     """Per-joint decimation of tau and of every column of W with ``scipy.signal.decimate(zero_phase=True)``
     (examples/staubli_TX40/identification.py:186-204, examples/tiago/identification.py:142-187).
     Returns (list of W blocks, list of tau blocks).  Block i of W is ``W[i*nj:(i+1)*nj]`` with nj taken from tau, as in
     the scripts (when tau is longer than W's joint blocks the W blocks are offset and the last one is shorter -- kept).
     Every (block, column) sequence is one device thread running SciPy's sosfiltfilt recurrences (SURVEY 8f-1);
-    equal-length blocks share a launch."""
+    equal-length blocks share a launch.
+
+    A ``GpuMatrix`` W (``param["device_resident"]``) stays in HBM: the blocks come back as GpuMatrix views and device
+    vectors (for :func:`reject_rows`), nothing is copied to the host."""
+    if isinstance(W, GpuMatrix):
+        return _decimate_device(W, tau, nblocks, q, stages)
     W = np.asarray(W, dtype=np.float64)
     tau = np.asarray(tau, dtype=np.float64)
     nj = tau.shape[0] // nblocks

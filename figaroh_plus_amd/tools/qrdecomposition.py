@@ -32,9 +32,13 @@ def rfactor(W, tau=None, col_idx=None, block_weight=None):
     d_idx = None if col_idx is None else index_to_device(col_idx)
     d_tau = None
     if tau is not None:
-        tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(-1)
-        if tau.shape[0] != Wd.rows:
-            raise ValueError("tau has %d entries, W has %d rows" % (tau.shape[0], Wd.rows))
+        if hasattr(tau, "ptr"):  # a device vector (e.g. reject_rows on a device-resident W): stays where it is
+            ntau = int(tau.size)
+        else:
+            tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(-1)
+            ntau = tau.shape[0]
+        if ntau != Wd.rows:
+            raise ValueError("tau has %d entries, W has %d rows" % (ntau, Wd.rows))
         d_tau = vector_to_device(tau)
     nc = n + (1 if tau is not None else 0)
     d_R = _lib.DeviceArray((nc * nc,), np.float64)

@@ -185,6 +185,13 @@ int figh_tsqr(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col
 int figh_tsqr_structured(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
                          const double *d_tau, const double *h_block_weight, int nblocks, const int32_t *h_first_col,
                          int nfirst, double *d_R_out);
+/* Order-preserving row rejection (examples/staubli_TX40/identification.py:207-233, examples/tiago/identification.py:170-187:
+ * samples whose joint velocity is below a threshold are removed from a joint's block of W and tau): the rows r of d_W
+ * (rows x cols, leading dimension ldw) with |d_W[r, key_col]| >= threshold are copied, in order, to d_W_out (leading
+ * dimension ld_out; room for `rows` rows) and, if given, d_tau[r] to d_tau_out; *h_count_out = the number of kept rows
+ * (the call synchronises to return it). */
+int figh_compact_rows(const double *d_W, int64_t rows, int cols, int64_t ldw, const double *d_tau, int key_col,
+                      double threshold, double *d_W_out, int64_t ld_out, double *d_tau_out, int64_t *h_count_out);
 /* The rank decision and the regrouped column order on the device (qrdecomposition.py:215-236): d_perm receives
  * [i : |R_ii| > tol_qr, ascending] followed by the remaining i < n, followed by n .. nc-1 (the tau column); the regrouped
  * factorisation qr([W1 W2 tau]) is then figh_tsqr(d_R, nc, nc, d_perm, nc, NULL, ...) with no host round trip. */

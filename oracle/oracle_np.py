@@ -408,6 +408,31 @@ def wls_script(W_b, tau, phi_b, row_counts):
     return phi, std
 
 
+def essential_script(W_b, tau, params_base, std_xr, sig_ro_joint, row_counts, ratio_essential):
+    """The essential-parameter loop of examples/staubli_TX40/identification.py:354-399, statement for statement (dense
+    SIGMA replaced by its diagonal): while max(std) >= ratio * min(std) drop the parameter with the largest std%, OLS
+    (lstsq, 6 decimals) + relative_stdev, WLS with the variances ``sig_ro_joint`` of the FULL base set (the script fills
+    diag_SIGMA_e from sig_ro_joint, not from sig_ro_joint_e), std% from C_X_e."""
+    names = list(params_base)
+    W_ess = np.array(W_b, dtype=float)
+    std_e = np.asarray(std_xr, dtype=float)
+    w = np.repeat(1.0 / np.asarray(sig_ro_joint, dtype=float), row_counts)
+    out = {"iterations": 0}
+    while not (std_e.max() < ratio_essential * std_e.min()):
+        (i,) = np.where(np.isclose(std_e, std_e.max()))
+        del names[int(i[0])]
+        W_ess = np.delete(W_ess, i, 1)
+        phi_e_ols = np.around(np.linalg.lstsq(W_ess, tau, rcond=None)[0], 6)
+        std_e_ols = relative_stdev(W_ess, phi_e_ols, tau)
+        C = np.linalg.inv(W_ess.T @ (W_ess * w[:, None]))
+        phi_e_wls = np.around(C @ (W_ess.T @ (w * tau)), 6)
+        std_e = np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi_e_wls), 2)
+        out.update(phi_e_ols=phi_e_ols, std_e_ols=std_e_ols, phi_e_wls=phi_e_wls, std_e_wls=std_e.copy())
+        out["iterations"] += 1
+    out["params_essential"] = names
+    return out
+
+
 def weigthed_least_squares(nq, phi_b, W_b, tau_meas, tau_est, idx_tau_stop):
     """Library WLS of src/figaroh/identification/identification_tools.py:291-331,
     including its quirks (sigma is a norm, not a variance; re-solve inside the joint loop)."""

@@ -1765,3 +1765,79 @@ def test_pipeline_wls_against_oracle_formula(lib, oracle_lib, cfg, N, layout):
     assert np.abs(out["std_wls"] - std_ref)[ok].max() <= 0.011 + 1e-5 * np.abs(std_ref[ok]).max()
     if cfg == "cfg3_tiago" and layout == "block-compact":
         assert out["wls_source"] == "per-row-block triangles"
+
+
+# ------------------------------------------------------------------------------------------------ real-data chain in HBM
+def test_tx40_real_data_device_resident_chain(lib, monkeypatch):
+    """The known-answer replay of test_tx40_real_data_known_answers_hip with the regressor RESIDENT in HBM from K1 to
+    double_QR: regressor (TX40 coupling columns fused) -> two decimate-by-10 stages -> zero-velocity row rejection (device
+    stream compaction) -> elimination -> double_QR -> sigma -> OLS -> WLS -> essential-parameter loop.  GpuMatrix.numpy is
+    disabled while the chain runs: no copy of W (or of a derived matrix) to the host can happen unnoticed."""
+    from tx40_real_common import load_fixture, trajectories, tx40
+    from figaroh_plus_amd.device import GpuMatrix
+    from figaroh_plus_amd.identification.identification_tools import (decimate_joint_blocks, essential_parameters,
+                                                                       least_squares, low_pass_filter_data, reject_rows,
+                                                                       relative_stdev, weighted_least_squares_blocks)
+    from figaroh_plus_amd.tools.qrdecomposition import double_QR, rfactor
+    from figaroh_plus_amd.tools.regressor import _samples_to_device, build_regressor_device, eliminate_non_dynaffect
+    z, meta = load_fixture()
+    g, robot, param, params_std = tx40()
+    q, dq, ddq, tau = trajectories(z, robot, param, low_pass_filter_data)
+    N, d_q, d_v, d_a = _samples_to_device(robot.model, q, dq, ddq)
+    W, _ = build_regressor_device(robot, d_q, d_v, d_a, N, param, coupling=True)
+    assert isinstance(W, GpuMatrix) and W.shape == (6 * N, 87)
+
+    def no_copy(self, *a, **k):
+        raise AssertionError("the regressor was copied to the host inside the device-resident chain")
+    monkeypatch.setattr(GpuMatrix, "numpy", no_copy)
+    monkeypatch.setattr(GpuMatrix, "__array__", no_copy)
+    nj = tau.shape[0] // 6
+    W_head = GpuMatrix(W.buf, 6 * nj, W.cols, W.ld)  # the scripts cut W's joint blocks with tau's block length
+    W_list, tau_list = decimate_joint_blocks(W_head, tau, 6, q=10, stages=2)
+    W_, tau_, counts = reject_rows(W_list, tau_list, [i * 14 + 11 for i in range(6)], param["dq_lim_def"][:6])
+    assert counts == list(z["counts"]) and isinstance(W_, GpuMatrix)
+    W_e, params_r = eliminate_non_dynaffect(W_, params_std, 0.001)
+    assert isinstance(W_e, GpuMatrix) and params_r == meta["params_r"]
+    W_b, base_parameters, params_base, phi_b = double_QR(tau_, W_e, params_r)
+    assert isinstance(W_b, GpuMatrix) and params_base == meta["csv_expressions"]
+    csvv = z["csv"]
+    assert np.abs(phi_b - z["phi_b"]).max() <= 1.5e-6 and np.abs(phi_b - csvv[:, 0]).max() <= 4e-4
+    std = relative_stdev(W_b, phi_b, tau_)
+    assert np.abs(std - z["std_ols"]).max() <= 0.011 + 1e-4 * np.abs(z["std_ols"]).max()
+    phi_ols = np.around(least_squares(W_b, tau_), 6)
+    assert np.abs(phi_ols - z["phi_ols"]).max() <= 1.5e-6
+    phi_w, std_w, det = weighted_least_squares_blocks(W_b, tau_, phi_b, counts, return_details=True)
+    assert np.abs(phi_w - z["phi_wls"]).max() <= 1.5e-6 and np.abs(phi_w - csvv[:, 2]).max() <= 4e-4
+    ok = z["std_wls"] < 1e3
+    assert (np.abs(std_w - z["std_wls"])[ok] / z["std_wls"][ok]).max() <= 2e-3
+    # the essential-parameter loop on the two triangles of [W_b tau] (examples/staubli_TX40/identification.py:354-399)
+    R_ols = rfactor(W_b, tau=tau_)
+    ess = essential_parameters(R_ols, det["R_wls"], list(params_base), std_w, param["ratio_essential"], rows_total=W_b.rows)
+    monkeypatch.undo()
+    # ... against the script's loop on the host copy of the same W_b
+    Wb_h, tau_h = W_b.numpy(), tau_.to_host()[:W_b.rows]
+    ref = oracle_np.essential_script(Wb_h, tau_h, list(params_base), std_w, det["sigma2_joint"], counts,
+                                     param["ratio_essential"])
+    assert ess["iterations"] == ref["iterations"] and ess["params_essential"] == ref["params_essential"]
+    if ref["iterations"]:
+        assert np.abs(ess["phi_e_wls"] - ref["phi_e_wls"]).max() <= 1.5e-6
+        assert np.abs(ess["phi_e_ols"] - ref["phi_e_ols"]).max() <= 1.5e-6
+        fin = np.isfinite(ref["std_e_wls"]) & (np.abs(ref["std_e_wls"]) < 1e3)
+        assert np.abs(ess["std_e_wls"] - ref["std_e_wls"])[fin].max() <= 0.011 + 2e-3 * np.abs(ref["std_e_wls"][fin]).max()
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(1, 3, 3), (63, 5, 8), (64, 87, 87), (65, 87, 90), (4496, 87, 87), (20011, 14, 16)])
+def test_compact_rows_matches_numpy(lib, rows, cols, ld):
+    from figaroh_plus_amd.device import GpuMatrix
+    rng = np.random.default_rng(rows + cols)
+    W = rng.standard_normal((rows, ld))
+    tau = rng.standard_normal(rows)
+    key, thr = cols // 2, 0.6
+    dW = GpuMatrix(lib.DeviceArray.from_host(W.reshape(-1)), rows, cols, ld)
+    d_tau = lib.DeviceArray.from_host(tau)
+    out = GpuMatrix.empty(rows, cols)
+    d_to = lib.DeviceArray((rows,), np.float64)
+    kept = lib.compact_rows(dW.ptr, rows, cols, ld, d_tau.ptr, key, thr, out.ptr, cols, d_to.ptr)
+    keep = np.abs(W[:, key]) >= thr
+    assert kept == int(keep.sum())
+    assert np.array_equal(out.numpy()[:kept], W[keep][:, :cols]) and np.array_equal(d_to.to_host()[:kept], tau[keep])

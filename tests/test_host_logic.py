@@ -278,3 +278,36 @@ def test_set_missing_params_setting_matches_reference():
         after = fx["model_after"]
         assert model.lowerPositionLimit.tolist() == after["lower"] and model.upperPositionLimit.tolist() == after["upper"]
         assert model.velocityLimit.tolist() == after["velocity"] and model.effortLimit.tolist() == after["effort"]
+
+
+def test_essential_parameters_from_triangles_equals_script_loop():
+    """identification_tools.essential_parameters (the loop of examples/staubli_TX40/identification.py:354-399 run on the two
+    small triangles of a pass) against the oracle's statement-for-statement loop on the full W_b: same parameters dropped in
+    the same order, same rounded estimates.  Host only: the triangles come from LAPACK here."""
+    import oracle_np
+    from figaroh_plus_amd.identification.identification_tools import essential_parameters
+    rng = np.random.default_rng(12)
+    counts = [400, 380, 410, 395]
+    m, r = sum(counts), 9
+    W_b = rng.standard_normal((m, r)) * np.array([1, 1, 1, 1, 0.05, 1, 0.02, 1, 0.01])  # three poorly excited parameters
+    phi_true = rng.uniform(0.5, 2.0, r)
+    noise = np.repeat([0.05, 0.1, 0.2, 0.07], counts)
+    tau = W_b @ phi_true + noise * rng.standard_normal(m)
+    names = ["p%d" % i for i in range(r)]
+    phi_b = np.around(np.linalg.lstsq(W_b, tau, rcond=None)[0], 6)
+    sig2, a = [], 0
+    for n in counts:
+        sig2.append(np.linalg.norm(tau[a:a + n] - W_b[a:a + n] @ phi_b) ** 2 / n)
+        a += n
+    phi_w, std_w = oracle_np.wls_script(W_b, tau, phi_b, counts)
+    ref = oracle_np.essential_script(W_b, tau, names, std_w, sig2, counts, 30.0)
+    assert ref["iterations"] >= 2
+    sw = np.repeat(1.0 / np.sqrt(sig2), counts)
+    R_ols = np.linalg.qr(np.c_[W_b, tau], mode="r")
+    R_wls = np.linalg.qr(np.c_[W_b * sw[:, None], tau * sw], mode="r")
+    got = essential_parameters(R_ols, R_wls, names, std_w, 30.0, rows_total=m)
+    assert got["params_essential"] == ref["params_essential"] and got["iterations"] == ref["iterations"]
+    assert np.abs(got["phi_e_ols"] - ref["phi_e_ols"]).max() <= 1.5e-6
+    assert np.abs(got["phi_e_wls"] - ref["phi_e_wls"]).max() <= 1.5e-6
+    assert np.abs(got["std_e_wls"] - ref["std_e_wls"]).max() <= 0.011
+    assert np.abs(got["std_e_ols"] - ref["std_e_ols"]).max() <= 0.011
