@@ -170,7 +170,11 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=None,
                     help="samples of the CPU baseline legs (default: 300000 for cfg2, 20000 for cfg3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch", "host"],
+                    help="rccl: device buffers over RCCL / xGMI; torch / host: host-staged through the control plane")
+    ap.add_argument("--rendezvous", default="torch", choices=["torch", "socket"],
+                    help="control plane of a multi-rank run (RCCL id exchange, barriers, max over ranks): torch.distributed "
+                         "(gloo) or figaroh_plus_amd.dist.SocketGroup (standard library only: no PyTorch in the process)")
     ap.add_argument("--placement-trials", type=int, default=1,
                     help="set-up (untimed): candidate allocations of W among which the one K1 writes fastest is kept "
                          "(IdentificationPipeline.placement_trials; 1 = take the first, the default since round 4: the fused "
@@ -220,13 +224,13 @@ def main():
     host_wait = args.host_wait or ("block" if world > 1 else "spin")
     _lib.check(lib.figh_host_wait_mode(1 if host_wait == "block" else 0))
     _lib.check(lib.figh_device_set(local_rank % _lib.device_count()))
-    exchange, xinfo = exchange_from_env(args.exchange)
+    exchange, xinfo = exchange_from_env(args.exchange, rendezvous=args.rendezvous)
+    group = getattr(exchange, "control", None)  # the control plane of the run (None for one rank)
 
     def barrier():
         _lib.synchronize()
         if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
+            group.barrier()
 
     fixture, model_name, n_config, chunk = CONFIGS[args.config]
     scaling = args.scaling or ("weak" if args.config == "cfg2" else "strong")
@@ -283,11 +287,7 @@ def main():
     _lib.profile_enable(False)
     dt_rank = dt
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max(group.all_gather_object(dt))
 
     # sanity: the step produced the reference's structural result (cfg3 at 1e6 samples: four dependent pivots grow past
     # TOL_QR like sqrt(N), LAPACK agrees -- DESIGN.md section 4 -- so only the eliminated columns are compared there)

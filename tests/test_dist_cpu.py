@@ -175,3 +175,51 @@ def test_rccl_local_setup_failure_fails_fast(tmp_path):
         mp.spawn(_setup_worker, args=(2, port, str(tmp_path), "init_local_failure"), nprocs=2, join=True)
     assert "exit code 3" in str(e.value) or "exitcode" in str(e.value).lower()
     assert not os.path.exists(tmp_path / "rank1.json")
+
+
+def _socket_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import json
+    from figaroh_plus_amd import dist as fd
+
+    ex, info = fd.exchange_from_env("rccl", rendezvous="socket")  # (no HIP device here: host-staged, decided collectively)
+    rng = np.random.default_rng(100 + rank)
+    mine = rng.standard_normal(7)
+    total = ex.allreduce_sum_host(mine)
+    stack = ex.allgather_host(np.full((3, 3), float(rank)))
+    objs = ex.control.all_gather_object({"rank": rank})
+    top = ex.control.broadcast_object("from %d" % rank, src=world - 1)
+    ex.barrier()
+    json.dump({"collective": info["collective"], "kind": type(ex).__name__, "total": total.tolist(), "mine": mine.tolist(),
+               "stack": stack.tolist(), "objs": objs, "top": top, "torch_loaded": "torch" in sys.modules},
+              open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+    ex.close()
+
+
+@pytest.mark.timeout(120)
+def test_socket_rendezvous_needs_no_torch(tmp_path):
+    """exchange_from_env(rendezvous="socket"): the control plane and the host-staged exchange over plain TCP through rank 0
+    (figaroh_plus_amd.dist.SocketGroup) -- three ranks, identical sums and stacks everywhere, PyTorch never imported."""
+    import json
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_socket_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
+    want = np.sum([r["mine"] for r in res], axis=0)
+    for r in res:
+        assert r["kind"] == "SocketExchange" and "socket control plane host-staged" in r["collective"]
+        assert np.array_equal(np.array(r["total"]), np.array(res[0]["total"]))  # bit-identical on every rank
+        assert np.abs(np.array(r["total"]) - want).max() <= 1e-15
+        assert np.array(r["stack"]).shape == (world, 3, 3) and [s[0][0] for s in r["stack"]] == [0.0, 1.0, 2.0]
+        assert r["objs"] == [{"rank": k} for k in range(world)] and r["top"] == "from %d" % (world - 1)
+        assert not r["torch_loaded"]

@@ -1281,6 +1281,37 @@ def test_bench_two_ranks_share_the_device(lib):
     assert d["config"]["result_matches_reference"] is True
 
 
+def test_bench_two_ranks_socket_rendezvous(lib):
+    """bench.py with --rendezvous socket, launched WITHOUT torch.distributed.run: two plain processes with RANK / WORLD_SIZE /
+    MASTER_* in their environment (any launcher can do that), control plane = figaroh_plus_amd.dist.SocketGroup.  Both ranks
+    share the box's one GPU, so the exchange is negotiated down to the host-staged one; the line is the weak-scaling one."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        for k in [k for k in env if k.startswith("FIGH_")]:
+            del env[k]
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                                       "--warmup", "2", "--samples", "200000", "--rendezvous", "socket"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-2000:] + outs[1][-2000:]
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["samples_total"] == 400000
+    assert "socket control plane" in d["config"]["collective"] and "share a device" in d["config"]["collective"]
+    assert d["config"]["result_matches_reference"] is True
+
+
 def test_tsqr_randomised_stress(lib):
     """tools/tsqr_stress.py: 60 random cases over the blocked-kernel range (column counts on and off the geometry
     boundaries, ragged and short row counts, column gathers, tau, row-block weights, zero leading blocks, exactly
