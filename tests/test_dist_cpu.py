@@ -75,6 +75,45 @@ def test_two_rank_exchange_matches_single_process(tmp_path, oracle_lib):
     assert np.abs(phi - g["phi_pinv"]).max() <= 1e-8 * np.abs(g["phi_pinv"]).max()
 
 
+def _hip_fixture_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from figaroh_plus_amd.dist import TorchExchange
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = TorchExchange()
+    z = np.load(os.path.join(GOLD, "hip_triangles_ur10.npz"))
+    stack = ex.allgather_host(z["R_rank%d" % rank])  # what stack_triangles hands to figh_tsqr_merge on every rank
+    nc = stack.shape[1]
+    Rm = np.linalg.qr(stack.reshape(world * nc, nc), mode="r")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), R=Rm)
+    ex.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_exchange_of_recorded_hip_triangles(tmp_path):
+    """The same exchange fed with factors the HIP path produced (tests/golden/hip_triangles_ur10.npz, recorded on an MI355X
+    by tools/record_hip_triangles.py: the level-0 + merge triangle of each of two sample shards, and the one-process
+    triangle): the stack of the two device triangles reduces to the one-process device triangle (|R| to 1e-12), the rank
+    decision on it is the golden base set."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_hip_fixture_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz")["R"], np.load(tmp_path / "rank1.npz")["R"]
+    assert np.array_equal(r0, r1)
+    z = np.load(os.path.join(GOLD, "hip_triangles_ur10.npz"))
+    one = z["R_one_process"]
+    g = np.load(os.path.join(GOLD, "cfg2_ur10.npz"))
+    d = np.abs(np.diag(r0))[:-1]
+    assert [i for i in range(len(d)) if d[i] > 1e-8] == list(g["idx_base"])
+    first_dep = min(i for i in range(len(d)) if d[i] <= 1e-8)
+    assert np.abs(np.abs(r0[:first_dep]) - np.abs(one[:first_dep])).max() <= 1e-12 * np.abs(one).max()
+    assert np.abs(r0.T @ r0 - one.T @ one).max() <= 1e-12 * np.abs(one.T @ one).max()
+
+
 def _setup_worker(rank, world, port, out_dir, scenario):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
