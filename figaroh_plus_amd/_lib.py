@@ -73,7 +73,7 @@ SIGNATURES = {
     "figh_tsqr_selected_blocks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "figh_block_triangle_residuals": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "figh_block_rows_residuals": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, C.c_int, C.c_void_p, C.c_void_p]),
     "figh_tsqr_selected": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "figh_regressor_tsqr_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -441,8 +441,8 @@ def tsqr_selected_blocks(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_e
                          tol_qr, d_sel, d_R, block_off=None, block_ld=None, d_block_tri=None):
     """tsqr_selected with one column list per row block (joint-torque regressor of a tree, figh.h); ``counts``: int32
     host array, one entry per row block; ``block_off`` / ``block_ld``: the block-compact W (element offsets, int64, and
-    leading dimensions, int32, per row block); ``d_block_tri`` ((nblocks + 1) nc^2 doubles, optional) receives the embedded
-    per-row-block triangles."""
+    leading dimensions, int32, per row block); ``d_block_tri`` (optional) receives the compact stack of the embedded
+    per-row-block triangles (figh.h)."""
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     off = ld = None
     if block_off is not None:
@@ -456,9 +456,10 @@ def tsqr_selected_blocks(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_e
                                            d_block_tri.ptr if d_block_tri is not None else None))
 
 
-def block_triangle_residuals(d_tri, count, nc, d_v, d_r2):
-    """d_r2[b] = || R_b v ||^2 over ``count`` stacked nc x nc triangles (figh.h)."""
-    check(load().figh_block_triangle_residuals(d_tri.ptr, count, nc, d_v.ptr, d_r2.ptr))
+def block_rows_residuals(d_rows, row_off, nc, d_v, d_r2):
+    """d_r2[b] = sum over rows [row_off[b], row_off[b+1]) of (row . v)^2 (figh.h); ``row_off``: nblocks + 1 ints."""
+    ro = _i32(row_off)
+    check(load().figh_block_rows_residuals(d_rows.ptr, len(ro) - 1, ro.ctypes.data_as(_c_int32_p), nc, d_v.ptr, d_r2.ptr))
 
 
 def regressor_tsqr_fused(model, flags, N, d_q, d_v, d_a, d_W, ldw, d_colsq, d_kept, n, d_tau, tol_qr, d_R):

@@ -1237,61 +1237,81 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         nmax = std::max(nmax, h_counts[j] + (d_tau ? 1 : 0));
     }
     const size_t tri = sizeof(double) * (size_t)nc * nc;
-    // the embedded per-row-block triangles: the caller's buffer when it wants to keep them (weighted solve afterwards:
-    // figh_block_triangle_residuals + figh_tsqr over the stack with row-block weights), else a library workspace
-    double *stack = d_block_tri ? d_block_tri : static_cast<double *>(workspace(tri * (size_t)(nblocks + 1), 26));
+    // The per-row-block triangles, embedded into the kept column set, are stacked COMPACTLY: block j contributes its
+    // n_j (+ 1 with tau) rows only -- TIAGo: 650 rows instead of 24 x 241 -- and the stack is one small tall matrix that a
+    // single workgroup factors (one launch; the 24 full-size triangles took five pair-merge levels, 3.4 ms of the 17 ms step).
+    // It lives in the caller's buffer when the caller wants to keep it (weighted solve afterwards: figh_block_rows_residuals
+    // + figh_tsqr over the rows with per-row weights), else in a library workspace.
+    long rows_total = 0;
+    for (int j = 0; j < nblocks; ++j)
+        if (h_counts[j] > 0 || d_tau) rows_total += h_counts[j] + (d_tau ? 1 : 0);
+    double *stack = d_block_tri ? d_block_tri
+                                : static_cast<double *>(workspace(sizeof(double) * (size_t)(rows_total + nc + 1) * nc, 26));
     const int64_t cap_b = std::max(figh_tsqr_level0_capacity(nmax), figh_tsqr_level0_capacity(std::min(nmax, 80)));
     double *tri_b = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax * cap_b, 23));
     double *Rb = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax, 24));
-    if (!stack || !tri_b || !Rb) return FIGH_ERR_ALLOC;
-    long have = 0, off = 0;
+    double *one = static_cast<double *>(workspace(tri, 16));
+    if (!stack || !tri_b || !Rb || !one) return FIGH_ERR_ALLOC;
+    long row_off = 0, off = 0;
     for (int j = 0; j < nblocks; ++j) {
         const int nj = h_counts[j], ncj = nj + (d_tau ? 1 : 0);
         // (block-compact W, FIGH_FLAG_COMPACT_BLOCKS: every row block is a matrix of its own; d_cols are then columns of it)
         const double *Wj = h_block_off ? d_W + h_block_off[j] : d_W + (int64_t)j * rows_b * ldw;
         const int64_t ldj = h_block_ld ? h_block_ld[j] : ldw;
         const double *tj = d_tau ? d_tau + (int64_t)j * rows_b : nullptr;
-        if (nj == 0) {  // (only tau in this block: its norm still counts)
-            off += nj;
-            if (!d_tau) {
-                if (d_block_tri) {  // (kept stacks have one slot per row block: an empty one is a zero triangle)
-                    FIGH_HIP(hipMemsetAsync(stack + (size_t)have * nc * nc, 0, tri, stream()));
-                    ++have;
-                }
-                continue;
-            }
-        }
+        if (nj == 0 && !d_tau) continue;  // (nothing of this block is kept)
         int64_t cnt = 0;
         if (nj > 0) {
             if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr))
                 return rc;
         } else {
-            // a 1 x 1 "matrix": the tau rows alone, through the same kernel with tau as its only column
+            // (only tau in this block: its norm still counts) a 1 x 1 "matrix", the tau rows alone, through the same
+            // kernel with tau as its only column
             if (int rc = figh_tsqr_level0(tj, rows_b, 1, nullptr, 1, nullptr, nullptr, 0, tri_b, cap_b, &cnt, nullptr)) return rc;
         }
         if (cnt == 1) FIGH_HIP(hipMemcpyAsync(Rb, tri_b, sizeof(double) * (size_t)ncj * ncj, hipMemcpyDeviceToDevice, stream()));
         else if (int rc = tsqr_reduce(tri_b, cnt, ncj, Rb)) return rc;
-        if (int rc = embed_force_triangle(Rb, ncj, nj, d_pos + off, nc, n, stack + (size_t)have * nc * nc)) return rc;
-        ++have;
+        // (the embedding zero-fills nc rows from its offset and writes the block's ncj rows: the rows behind them belong to
+        // the next block, whose own embedding follows in stream order; the buffer ends nc rows behind the last block)
+        if (int rc = embed_force_triangle(Rb, ncj, nj, d_pos + off, nc, n, stack + (size_t)row_off * nc)) return rc;
+        row_off += ncj;
         off += nj;
     }
-    if (have == 0) {
+    if (row_off == 0) {
         FIGH_HIP(hipMemsetAsync(stack, 0, tri, stream()));
-        have = 1;
+        row_off = nc;
     }
-    return tsqr_reduce_stack(stack, have, nc, n, tol_qr, d_R_out);
+    if (nc > 80) {
+        {
+            ProfileScope scope("tsqr_block_stack");
+            if (int rc = launch_tsqr_wide_single(stack, row_off, nc, nullptr, nc, nc, one)) return rc;
+        }
+        if (tol_qr < 0.0) {
+            FIGH_HIP(hipMemcpyAsync(d_R_out, one, tri, hipMemcpyDeviceToDevice, stream()));
+            return FIGH_OK;
+        }
+        return reveal_triangle(one, nc, n, tol_qr, d_R_out);
+    }
+    int64_t nw = 0;
+    double *Rws = nullptr;
+    if (int rc = figh_tsqr_level0(stack, row_off, nc, nullptr, nc, nullptr, nullptr, 0, nullptr, 0, &nw, &Rws)) return rc;
+    return tsqr_reduce_stack(Rws, nw, nc, n, tol_qr, d_R_out);
 }
 
-// r2[b] = || R_b v ||^2 for `count` stacked nc x nc upper triangles: one workgroup per triangle, rows over the threads,
-// fixed-order tree (deterministic)
-__global__ __launch_bounds__(256) void triangle_residuals_kernel(const double *__restrict__ Rs, const int nc,
-                                                                 const double *__restrict__ v, double *__restrict__ r2) {
+// r2[b] = sum over the rows [off[b], off[b+1]) of a stacked matrix of (row . v)^2: one workgroup per block, rows over the
+// threads, fixed-order tree (deterministic)
+struct BlockOffsets {
+    int off[kMaxJoints + 1];
+};
+__global__ __launch_bounds__(256) void block_rows_residuals_kernel(const double *__restrict__ Rs, const BlockOffsets bo,
+                                                                   const int nc, const double *__restrict__ v,
+                                                                   double *__restrict__ r2) {
     __shared__ double sm[256];
-    const double *R = Rs + (size_t)blockIdx.x * nc * nc;
+    const int lo = bo.off[blockIdx.x], hi = bo.off[blockIdx.x + 1];
     double s = 0.0;
-    for (int k = threadIdx.x; k < nc; k += 256) {
+    for (int k = lo + threadIdx.x; k < hi; k += 256) {
         double d = 0.0;
-        for (int c = k; c < nc; ++c) d += R[(size_t)k * nc + c] * v[c];
+        for (int c = 0; c < nc; ++c) d += Rs[(size_t)k * nc + c] * v[c];
         s += d * d;
     }
     sm[threadIdx.x] = s;
@@ -1303,12 +1323,18 @@ __global__ __launch_bounds__(256) void triangle_residuals_kernel(const double *_
     if (threadIdx.x == 0) r2[blockIdx.x] = sm[0];
 }
 
-int figh_block_triangle_residuals(const double *d_tri, int count, int nc, const double *d_v, double *d_r2) {
-    FIGH_REQUIRE(d_tri && d_v && d_r2, "NULL device pointer");
-    FIGH_REQUIRE(count >= 1 && nc >= 1 && nc <= 1024, "bad shape");
+int figh_block_rows_residuals(const double *d_rows, int nblocks, const int32_t *h_row_off, int nc, const double *d_v,
+                              double *d_r2) {
+    FIGH_REQUIRE(d_rows && h_row_off && d_v && d_r2, "NULL pointer");
+    FIGH_REQUIRE(nblocks >= 1 && nblocks <= kMaxJoints && nc >= 1 && nc <= 1024, "bad shape");
+    BlockOffsets bo;
+    for (int b = 0; b <= nblocks; ++b) {
+        FIGH_REQUIRE(h_row_off[b] >= 0 && (b == 0 || h_row_off[b] >= h_row_off[b - 1]), "row offsets must not decrease");
+        bo.off[b] = h_row_off[b];
+    }
     if (int rc = ensure_device()) return rc;
-    ProfileScope scope("triangle_residuals");
-    hipLaunchKernelGGL(triangle_residuals_kernel, dim3((unsigned)count), dim3(256), 0, stream(), d_tri, nc, d_v, d_r2);
+    ProfileScope scope("block_rows_residuals");
+    hipLaunchKernelGGL(block_rows_residuals_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream(), d_rows, bo, nc, d_v, d_r2);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }

@@ -134,7 +134,7 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
         TColumn<8, KK>::dot(acc0, acc1, tr, vg);
     }
     double inv, tfac;
-    householder_scalars(alpha, sigma, inv, tfac);
+    householder_scalars3(alpha, sigma, inv, tfac);
     // w_c = tau (R_kc + v^T X_c); the pivot lane gets w = alpha - beta, i.e. R_kk = alpha - w = beta
     // (frozen columns c < KK: w = 0; their row entry rk is a structural zero of the diagonal block and stays one)
     const double wj = (c >= KK) ? (rk + d * inv) * tfac : 0.0;

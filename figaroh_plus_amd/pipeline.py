@@ -474,7 +474,7 @@ class IdentificationPipeline:
         """Device buffer for the per-row-block triangles of figh_tsqr_selected_blocks (kept for the weighted solve)."""
         if not wls:
             return None
-        need = (nblocks + 1) * nc * nc
+        need = (nblocks + 2) * nc * nc  # (the compact stack is at most nblocks nc rows + nc + 1 rows of slack)
         buf = getattr(self, "_d_block_tri", None)
         if buf is None or buf.size < need:
             buf = self._d_block_tri = _lib.DeviceArray((need,), np.float64)
@@ -506,15 +506,18 @@ class IdentificationPipeline:
         d_Rw = _lib.DeviceArray(((nb_par + 1) * (nb_par + 1),), np.float64)
         kept = np.flatnonzero(self._kept_cache[0])
         if getattr(self, "_have_block_tri", False):
+            # the compact stack of the pass: block j holds its n_j + 1 triangle rows over the kept columns + tau
             tri = self._d_block_tri
+            counts = np.asarray(self._block_cache[1], dtype=np.int64) + 1
+            row_off = np.concatenate([[0], np.cumsum(counts)])
             v = np.zeros(nc)
             v[base] = phi_b
             v[n] = -1.0
-            _lib.block_triangle_residuals(tri, nblocks, nc, _lib.DeviceArray.from_host(v), d_r2)
+            _lib.block_rows_residuals(tri, row_off, nc, _lib.DeviceArray.from_host(v), d_r2)
             r2 = ex.sum_columns(d_r2, nblocks)
             sig2 = r2 / (rows_blk * ex.world_size)
             d_cols = _lib.DeviceArray.from_host(np.r_[base, n].astype(np.int32))
-            _lib.tsqr(tri, nblocks * nc, nc, d_cols, nb_par + 1, None, 1.0 / np.sqrt(sig2), d_Rw)
+            _lib.tsqr(tri, int(row_off[-1]), nc, d_cols, nb_par + 1, None, np.repeat(1.0 / np.sqrt(sig2), counts), d_Rw)
             source = "per-row-block triangles"
         else:
             if self._compact is not None:

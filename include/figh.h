@@ -256,19 +256,21 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
  * kept column set, and the nblocks triangles are merged.  Same outputs as figh_tsqr_selected.  h_block_off / h_block_ld
  * (host, nblocks entries each, both or neither): the block-compact W of FIGH_FLAG_COMPACT_BLOCKS -- row block j is the
  * rows / nblocks x h_block_ld[j] matrix at d_W + h_block_off[j] and d_cols index ITS columns; ldw is then unused.
- * d_block_tri (nullable; (nblocks + 1) nc^2 doubles): receives the nblocks embedded per-row-block triangles, slot j = row
- * block j, for a weighted solve afterwards (figh_block_triangle_residuals, then figh_tsqr over the stack with row-block
- * weights: the rows of W are not read again). */
+ * The nblocks embedded triangles are stacked compactly -- block j contributes its h_counts[j] (+ 1 with tau) rows over the
+ * nc kept columns [+ tau] -- and factored as one small tall matrix.  d_block_tri (nullable; room for
+ * (sum_j (h_counts[j] + 1) + nc + 1) nc doubles) receives that stack, for a weighted solve afterwards
+ * (figh_block_rows_residuals, then figh_tsqr over its rows with one weight per row: W itself is not read again). */
 int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nblocks, const int32_t *h_counts, const int32_t *d_cols,
                               const int32_t *d_pos, const int64_t *h_block_off, const int32_t *h_block_ld,
                               const double *d_tau, double tol_qr, int32_t *d_sel, double *d_R_out, double *d_block_tri);
-/* Per-row-block residual norms from per-row-block triangles: d_tri holds `count` nc x nc upper triangles R_b of
- * [W_b,kept | tau_b] (what figh_tsqr_selected_blocks leaves in d_block_tri: row block b of the regressor, embedded into the
- * kept column set, tau last); with v = [phi over the kept columns; -1], d_r2[b] = || R_b v ||^2 = || tau_b - W_b phi ||^2 --
- * the per-joint variances of the weighted least squares (examples/staubli_TX40/identification.py:305-316,
- * identification_tools.py:291-331) without another pass over W. */
-int figh_block_triangle_residuals(const double *d_tri, int count, int nc, const double *d_v, double *d_r2);
+/* Per-row-block residual norms from the compact stack figh_tsqr_selected_blocks leaves in d_block_tri: block b occupies the
+ * rows [h_row_off[b], h_row_off[b+1]) (h_row_off[b] = sum over the blocks in front of b of their column count + 1 for tau;
+ * nblocks + 1 entries), every row over the nc = n + 1 kept columns [+ tau].  With v = [phi over the kept columns; -1],
+ * d_r2[b] = sum of (row . v)^2 = || tau_b - W_b phi ||^2 -- the per-joint variances of the weighted least squares
+ * (examples/staubli_TX40/identification.py:305-316, identification_tools.py:291-331) without another pass over W. */
+int figh_block_rows_residuals(const double *d_rows, int nblocks, const int32_t *h_row_off, int nc, const double *d_v,
+                              double *d_r2);
 /* figh_tsqr_merge followed by the rank decision and the regrouped factorisation as in figh_tsqr_selected (the cross-rank
  * reduction of the all-gathered per-rank triangles): columns k < n_free take part in the rank decision, the others (tau)
  * always count as base columns.  d_rows_out: (nc + 1) x nc. */
