@@ -525,12 +525,18 @@ __global__ __launch_bounds__(1024) void embed_force_triangle_kernel(const double
     for (int e = threadIdx.x; e < ncf * ncf; e += 1024) {
         const int r = e / ncf, c = e - r * ncf;
         if (c < r) continue;
-        const int col = c < nf ? fpos[c] : n;  // (c == nf: the tau column)
+        int col = c < nf ? fpos[c] : n;  // (c == nf: the tau column)
+        // (a caller that guessed too many force columns -- the count is speculative, verified afterwards -- reads entries the
+        // split kernel never wrote: zero-filled by the launcher, and in range whatever they hold)
+        col = col < 0 ? 0 : (col >= nc ? nc - 1 : col);
         out[(long)r * nc + col] = Rf[e];
     }
 }
 
 int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel) {
+    // the kernel writes as many entries as there are kept columns with slot >= 6; a caller's (speculative) count may be
+    // larger: what lies behind them must be valid column indices, not whatever the workspace held
+    FIGH_HIP(hipMemsetAsync(d_fsel, 0, sizeof(int) * 2 * (size_t)n, stream()));
     hipLaunchKernelGGL(split_force_columns_kernel, dim3(1), dim3(256), 0, stream(), d_kept, n, link_stride, d_fsel);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
@@ -1168,8 +1174,7 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
     const int n = n_expected, nf = nf_expected, ncf = nf + (d_tau ? 1 : 0);
     int *fsel = static_cast<int *>(workspace(sizeof(int) * 2 * (size_t)n, 22));
     if (!fsel) return FIGH_ERR_ALLOC;
-    hipLaunchKernelGGL(split_force_columns_kernel, dim3(1), dim3(256), 0, stream(), d_sel + 2, n, link_stride, fsel);
-    FIGH_HIP(hipGetLastError());
+    if (int rc = split_force_columns(d_sel + 2, n, link_stride, fsel)) return rc;  // (zero-fills behind the actual count)
     const int64_t rows_f = rows / 2;
     // ---- force rows: their own TSQR over nf columns, reduced to one triangle
     const int64_t cap_f = figh_tsqr_level0_capacity(ncf);

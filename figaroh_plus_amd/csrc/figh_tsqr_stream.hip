@@ -479,6 +479,18 @@ static int launch_stream(const double *Rs, long count, int nc, int n_free, doubl
         hipLaunchKernelGGL(poison_fill_kernel, dim3(256), dim3(256), 0, stream(), sbuf, want);
         FIGH_HIP(hipGetLastError());
     }
+    // Residency: consumers spin on their producers, so the whole grid must be co-resident.  The bound above (one workgroup
+    // per CU) is checked against what the runtime says this instantiation can hold (registers, LDS); a refusal sends the
+    // caller to the level-by-level reduction.  (A cooperative launch would make the runtime the guarantor -- it also covers
+    // CU masks -- but costs this 0.11 ms launch 20 us, measured: 0.129 against 0.110 ms; the level-by-level fallback,
+    // figh_tsqr_tree.hip, is launched that way.)
+    static int occ = -1;
+    if (occ < 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, tsqr_stream_kernel<NCC, FANR, 8>, 512, 0) != hipSuccess) v = 0;
+        occ = v;
+    }
+    if (occ < 1) return FIGH_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((tsqr_stream_kernel<NCC, FANR, 8>), dim3((unsigned)grid), dim3(512), 0, stream(), Rs, sbuf, d_out,
                        d_rows_out, plan, nc, n_free, tol);
     FIGH_HIP(hipGetLastError());

@@ -312,14 +312,26 @@ static int launch_tree(const double *Rs, long count, int nc, int n_free, double 
         if (!bufB) return FIGH_ERR_ALLOC;
     }
     static unsigned *counters = nullptr;
-    if (!counters) {
-        FIGH_HIP(hipMalloc(&counters, 8 * sizeof(unsigned)));
-        FIGH_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), stream()));
-    }
+    if (!counters) FIGH_HIP(hipMalloc(&counters, 8 * sizeof(unsigned)));
+    // zeroed before every launch (not left to the previous launch's epilogue: an aborted launch would leave them set)
+    FIGH_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), stream()));
     const unsigned grid = plan.nlevels > 0 ? (unsigned)plan.nb[0] : 1u;
-    hipLaunchKernelGGL((tsqr_tree_kernel<NCC, NRC, NW>), dim3(grid), dim3(64 * NW), 0, stream(), Rs, bufA, bufB, d_out, plan,
-                       nc, n_free, tol, d_rows_out, counters);
-    FIGH_HIP(hipGetLastError());
+    // cooperative launch: co-residency of the whole grid is the runtime's guarantee, or the launch is refused (the level
+    // counters are spun on by the workgroups of the next level)
+    const double *a_Rs = Rs;
+    double *a_A = bufA, *a_B = bufB, *a_out = d_out, *a_rows = d_rows_out;
+    TreePlan a_plan = plan;
+    int a_nc = nc, a_nf = n_free;
+    double a_tol = tol;
+    unsigned *a_cnt = counters;
+    void *args[] = {&a_Rs, &a_A, &a_B, &a_out, &a_plan, &a_nc, &a_nf, &a_tol, &a_rows, &a_cnt};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&tsqr_tree_kernel<NCC, NRC, NW>), dim3(grid),
+                                                    dim3(64 * NW), args, 0, stream());
+    if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorNotSupported || e == hipErrorInvalidConfiguration) {
+        (void)hipGetLastError();
+        return FIGH_ERR_UNSUPPORTED;
+    }
+    FIGH_HIP(e);
     return FIGH_OK;
 }
 

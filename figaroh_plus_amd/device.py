@@ -45,6 +45,11 @@ class GpuMatrix:
         return cls(_lib.DeviceArray.from_host(arr.reshape(-1)), arr.shape[0], arr.shape[1])
 
     def numpy(self):
+        if getattr(self, "compact", None) is not None:
+            # (IdentificationPipeline(w_layout="block-compact"): rows / cols describe the regressor, the buffer holds
+            # N sum_j ld_j doubles -- reading rows * ld doubles would run far past the allocation)
+            raise ValueError("block-compact W is not a dense rows x ld matrix: read its row blocks through .compact "
+                             "(element offsets, leading dimensions)")
         if self.ld == self.cols:
             out = np.empty((self.rows, self.cols))
             if out.size:

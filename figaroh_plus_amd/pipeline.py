@@ -22,17 +22,27 @@ from .tools.regressor import build_regressor_device
 
 
 class Exchange:
-    """Single-process default: nothing to exchange."""
+    """Single-process default: nothing to exchange.  Also the BASE CLASS for user-supplied exchanges: a subclass overrides
+    ``sum_columns`` and ``stack_triangles`` (and sets ``world_size`` / ``rank``); ``sum_columns_device`` and ``collective``
+    have working defaults built on those."""
 
     world_size = 1
     rank = 0
-    collective = False  # run() then folds the rank decision into the local merge tree; the exchanges below are bypassed
+
+    @property
+    def collective(self):
+        """False: run() folds the rank decision into the local merge tree and bypasses the exchanges below."""
+        return self.world_size > 1
 
     def sum_columns(self, d_colsq, ncols):
         return d_colsq.to_host()
 
     def sum_columns_device(self, d_colsq, ncols):
-        """In place: d_colsq holds the sum over the ranks afterwards; nothing returns to the host."""
+        """In place: d_colsq holds the sum over the ranks afterwards.  Default: through ``sum_columns`` and one copy back
+        (an exchange written against the two-method interface keeps working); nothing to do for one rank."""
+        if self.world_size > 1:
+            total = np.ascontiguousarray(self.sum_columns(d_colsq, ncols), dtype=np.float64)
+            _lib.check(_lib.load().figh_memcpy_h2d(d_colsq.ptr, total.ctypes.data, total.nbytes))
 
     def stack_triangles(self, d_R, nc):
         return d_R, 1
@@ -607,6 +617,9 @@ class IdentificationPipeline:
     def device_columns(self, ref_cols):
         """Column indices of the HBM-resident ``self.W`` that hold the reference's columns ``ref_cols`` (trees keep W
         link-padded: 16 columns per link, reference column c at 16 (c // 14) + c % 14)."""
+        if getattr(self, "_compact", None) is not None:
+            raise ValueError("block-compact W has no global column numbering: row block j is its own N x 16 |subtree_j| "
+                             "matrix (pipe.W.compact = (element offsets, leading dimensions))")
         c = np.asarray(ref_cols, dtype=np.int64)
         return (c // 14) * 16 + c % 14 if getattr(self, "_padded", False) else c
 

@@ -668,6 +668,23 @@ def test_structured_tsqr_entry_points_on_synthetic_matrices(lib, stride, with_ta
         run(lib.tsqr_selected_wrench, Wref, lambda kept: (int(np.count_nonzero(kept % 14 >= 6)),))
         run(lib.tsqr_selected_wrench, Wref, lambda kept: (0,))                      # nf unknown: plain path
         run(lib.tsqr_selected_wrench, Wref[:6 * 40], lambda kept: (int(np.count_nonzero(kept % 14 >= 6)),))  # too few rows
+        # a STALE speculative count (the caller verifies it afterwards and discards the triangle): too large reads list
+        # entries the split kernel never wrote, too small drops force columns -- neither may fault or leave the selection
+        # wrong
+        for delta in (+5, -3):
+            d_W = lib.DeviceArray.from_host(to_device_layout(Wref).reshape(-1))
+            d_cs = lib.DeviceArray.from_host((Wref ** 2).sum(axis=0))
+            d_tau = lib.DeviceArray.from_host(tau) if with_tau else None
+            d_sel = lib.DeviceArray((2 + 2 * ncols,), np.int32)
+            kept = np.flatnonzero((Wref ** 2).sum(axis=0) >= 1e-6)
+            n, nfk = len(kept), int(np.count_nonzero(kept % 14 >= 6))
+            nc = n + (1 if with_tau else 0)
+            d_R = lib.DeviceArray((nc * nc,))
+            lib.tsqr_selected_wrench(d_W, rows, ld, d_cs, ncols, 1e-6, stride, n, nfk + delta, d_tau, -1.0, d_sel, d_R)
+            lib.synchronize()
+            sel = d_sel.to_host()
+            assert sel[0] == n and np.array_equal(sel[2:2 + n], (kept // 14) * stride + kept % 14)
+            assert np.all(np.isfinite(d_R.to_host()))
     # ---- nb row blocks with their own column subsets (one of them empty)
     nb = 7
     Nb2 = 700
