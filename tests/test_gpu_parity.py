@@ -1732,6 +1732,45 @@ def test_fused_pass_equals_two_launch_pass(lib, golden_ur10, N):
     assert c_["idx_base"] == b_["idx_base"] and np.abs(c_["phi_ls"] - b_["phi_ls"]).max() <= 1e-10 * np.abs(b_["phi_ls"]).max()
 
 
+@pytest.mark.parametrize("flags", [dict(has_friction=True), dict(has_actuator_inertia=True, has_joint_offset=True)])
+def test_fused_pass_with_friction_inertia_offset_columns(lib, golden_ur10, oracle_lib, flags):
+    """The fused launch with the fv / fs or Ia / off columns switched on (regressor.py:55-70,84-87: the producer's own-link
+    columns) -- 61 kept columns + tau, i.e. wider triangles and four consumer waves per workgroup instead of six: W against
+    the oracle, the pass against the two-launch pass, and that the fused launch is what ran."""
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    g = golden_ur10
+    param = dict(g.param, **flags)
+    robot = g.robot()
+    params_std = robot.get_standard_parameters(param)
+    N = 30000 + 11
+    q, v, a, rng, _ = _ur10_problem(g, N, 31)
+    W_ref = _oracle_W(g, oracle_lib, q, v, a, param=param)
+    phi = rng.uniform(0.1, 1.0, W_ref.shape[1])
+    tau = W_ref @ phi + 0.05 * rng.standard_normal(W_ref.shape[0])
+    outs = []
+    for fuse in (False, True):
+        pipe = IdentificationPipeline(robot, param, params_std=params_std, fuse=fuse)
+        pipe.set_samples(q, v, a, tau)
+        pipe.run()
+        out = pipe.run()
+        assert pipe.fused_passes == (1 if fuse else 0)
+        if fuse:
+            W = np.empty((pipe.W.rows, pipe.W.ld))
+            lib.check(lib.load().figh_memcpy_d2h(W.ctypes.data, pipe.W.buf.ptr, W.nbytes))
+            assert np.abs(W - W_ref).max() <= 1e-12 * np.abs(W_ref).max()
+        outs.append(out)
+    a_, b_ = outs
+    assert len(a_["params_r"]) == 61
+    assert a_["idx_e"] == b_["idx_e"] and a_["idx_base"] == b_["idx_base"] and a_["params_base"] == b_["params_base"]
+    assert np.abs(a_["col_norm"] - b_["col_norm"]).max() <= 1e-13 * a_["col_norm"].max()
+    # (the offset columns next to gravity make one base parameter nearly undetermined -- |phi| ~ 1e5 with random data: the
+    # two factorisations agree on it to its conditioning, and to 1e-9 on what the data do determine, the residual)
+    assert np.abs(a_["phi_ls"] - b_["phi_ls"]).max() <= 1e-4 * np.abs(a_["phi_ls"]).max()
+    assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * a_["residual_norm"]
+    ref = (W_ref * W_ref).sum(axis=0)
+    assert np.abs(b_["col_norm"] - ref).max() <= 1e-12 * ref.max()
+
+
 def test_fused_pass_triangle_against_lapack(lib, golden_ur10, oracle_lib):
     """The plain triangle of the fused launch (tol_qr < 0) against LAPACK's R of the oracle's [W_e tau]: R^T R to 1e-12."""
     g = golden_ur10

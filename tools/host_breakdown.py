@@ -17,7 +17,8 @@ def wrap(obj, name):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); marks.append((name, t0, time.perf_counter())); return r
     setattr(obj, name, g)
-wrap(_lib, "regressor_build"); wrap(_lib, "tsqr_selected"); wrap(IdentificationPipeline, "_finish")
+wrap(_lib, "regressor_build"); wrap(_lib, "tsqr_selected"); wrap(_lib, "regressor_tsqr_fused"); wrap(_lib, "select_columns")
+wrap(IdentificationPipeline, "_finish")
 lib = _lib.load()
 orig_d2h = lib.figh_memcpy_d2h
 class L:
