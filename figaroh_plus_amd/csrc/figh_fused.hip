@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
         lds_post(&ctrl->taken, tpick + 1);
         FUSED_TICK(c2);
         FUSED_ADD(9, c2 - c1);
-        tsqr2_panels<0, NCC, NRC, true, true>(S, first_nz, [](auto) {});
+        tsqr2_panels<0, NCC, NRC, false, true>(S, first_nz, [](auto) {});
         FUSED_TICK(c3);
         FUSED_ADD(10, c3 - c2);
         FUSED_ADD(12, 1);

@@ -101,6 +101,26 @@ void tsqr_level0_chain(long wgs, int chain_flags);
 // in force rows (d_fsel: n columns, then n positions in the kept list) and the force rows' triangle over all kept columns
 int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel);
 int embed_force_triangle(const double *d_Rf, int ncf, int nf, const int *d_fpos, int nc, int n, double *d_out);
+// figh_tsqr_group.hip: the narrow row blocks of a tree's joint-torque regressor as jobs of grouped launches
+struct Tsqr2Job {
+    const double *W;       // the block's rows (its own matrix in the block-compact layout)
+    const double *tau;     // nullable
+    const int *col_idx;    // n device columns of W
+    const int *pos;        // their positions in the kept column list (embedding)
+    double *tri;           // level-0 triangles of this job: nwaves x nc x nc
+    double *lvl[3];        // outputs of the merge levels (nb[l] x nc x nc each)
+    double *out;           // the job's rows of the compact stack (nc rows of ncfull doubles)
+    long rows, ldw;
+    int n, nc;             // columns, columns + tau
+    int wave0, nwaves;     // level 0: waves [wave0, wave0 + nwaves) of the launch
+    int wg0[3], nb[3];     // merge level l: workgroups [wg0[l], wg0[l] + nb[l]) of its launch (nb[l] == 0: level unused)
+    int nlevels;
+    int pad_;
+};
+}  // namespace figh
+#include <vector>
+namespace figh {
+int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus);
 // figh_linalg.hip: stack of `count` compact nc x nc triangles -> one; tol_qr >= 0: + rank decision and regrouped rows
 // ((nc + 1) x nc doubles, layout in figh.h, figh_tsqr_selected), else the plain triangle
 int tsqr_reduce_stack(const double *d_Rs, long count, int nc, int n_free, double tol_qr, double *d_out);

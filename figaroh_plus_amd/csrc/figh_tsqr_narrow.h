@@ -155,4 +155,77 @@ __device__ __forceinline__ void tsqr2_panels(Tsqr2State<NCC, NRC, RLAST> &S, con
     if constexpr (P + 1 < NCC) tsqr2_panels<P + 1, NCC, NRC, LDSRED, RLAST>(S, first_nz, after);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// tsqr_coop_kernel<NCC, NW>: the merge levels.  One workgroup of NW waves factors NW*64 stacked rows (about
+// NW*64/nc triangles) in ONE sweep of column steps instead of NW sequential 64-row tiles: every wave keeps its
+// own 64-row tile in registers, forms its part of x^T B, and the per-wave partial sums are combined through LDS
+// (fixed order: bit-reproducible).  A merge level is latency-bound (few waves on the chip), so its time is the
+// number of dependent column steps: nc per level here, against fan*nc for one wave walking `fan` tiles.
+// The triangle being built starts empty (alpha = 0), so row k is final at step k and is written straight out.
+template <int KK, int P, int NCC, int NW>
+__device__ __forceinline__ void tsqr_coop_step(double (&T)[NCC][16], const int nc, const int pad, const int lane_c,
+                                               const int lane_g, const int wave, double (*pw)[NW][16 * NCC],
+                                               double *__restrict__ Rg) {
+    constexpr int LIVE = NCC - P;
+    constexpr int kpos = 16 * P + KK;  // padded position of the pivot column
+    const int buf = kpos & 1;
+    // per-wave partial dot products of the pivot column (read in place through the DPP operand) with the live chunks
+#pragma unroll
+    for (int cc = 0; cc < LIVE; ++cc) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            fmac_bcast<KK>(s0, T[P][i], T[P + cc][i]);
+            fmac_bcast<KK>(s1, T[P][i + 1], T[P + cc][i + 1]);
+            fmac_bcast<KK>(s2, T[P][i + 2], T[P + cc][i + 2]);
+            fmac_bcast<KK>(s3, T[P][i + 3], T[P + cc][i + 3]);
+        }
+        const double dw = allreduce_rowgroups((s0 + s1) + (s2 + s3));
+        if (lane_g == 0) pw[buf][wave][16 * (P + cc) + lane_c] = dw;
+    }
+    __syncthreads();
+    // every wave sums the NW partials itself, in wave order (bit-reproducible): one barrier per column step; the
+    // partial buffers ping-pong so that the next step's stores cannot overtake a slow reader of this one
+    double d[LIVE];
+#pragma unroll
+    for (int cc = 0; cc < LIVE; ++cc) {
+        double s = pw[buf][0][16 * (P + cc) + lane_c];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += pw[buf][w][16 * (P + cc) + lane_c];
+        d[cc] = s;
+    }
+    const double sigma = row_bcast<KK>(d[0]);
+    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // uniform over the workgroup: same totals in every wave
+    // the output triangle starts empty, so alpha = 0: beta = -s, v = x / s, tau = 1
+    const double hq = -0.5 * sigma;
+    double rs = __builtin_amdgcn_rsq(sigma);
+    rs = rs * fma(hq * rs, rs, 1.5);
+    rs = rs * fma(hq * rs, rs, 1.5);
+    // w_j = x^T B_j / s for every lane-column (no masks): the pivot lane gets w = s, c = 1 and cancels itself, its
+    // R entry is -w = beta; finished and padding lane-columns hold (near) zeros.  Pivot chunk last: DPP source.
+#pragma unroll
+    for (int cc = LIVE - 1; cc >= 0; --cc) {
+        const double wj = d[cc] * rs;
+        const double ncj = -wj * rs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fmac_bcast<KK>(T[P + cc][i], T[P][i], ncj);
+        const int col = 16 * (P + cc) + lane_c - pad;
+        if (wave == 0 && lane_g == 0 && col >= kpos - pad) Rg[(long)(kpos - pad) * nc + col] = -wj;
+    }
+}
+
+template <int P, int NCC, int NW>
+__device__ __forceinline__ void tsqr_coop_panels(double (&T)[NCC][16], const int nc, const int pad, const int lane_c,
+                                                 const int lane_g, const int wave, double (*pw)[NW][16 * NCC],
+                                                 double *__restrict__ Rg) {
+#define FIGH_CSTEP(KK) \
+    if (16 * P + KK >= pad) tsqr_coop_step<KK, P, NCC, NW>(T, nc, pad, lane_c, lane_g, wave, pw, Rg);
+    FIGH_CSTEP(0) FIGH_CSTEP(1) FIGH_CSTEP(2) FIGH_CSTEP(3) FIGH_CSTEP(4) FIGH_CSTEP(5) FIGH_CSTEP(6) FIGH_CSTEP(7)
+    FIGH_CSTEP(8) FIGH_CSTEP(9) FIGH_CSTEP(10) FIGH_CSTEP(11) FIGH_CSTEP(12) FIGH_CSTEP(13) FIGH_CSTEP(14)
+    FIGH_CSTEP(15)
+#undef FIGH_CSTEP
+    if constexpr (P + 1 < NCC) tsqr_coop_panels<P + 1, NCC, NW>(T, nc, pad, lane_c, lane_g, wave, pw, Rg);
+}
+
+
 }  // namespace figh
