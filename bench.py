@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--no-wls", action="store_true",
                     help="cfg3: leave the weighted least squares (examples/staubli_TX40/identification.py:305-346) out of the "
                          "timed step (default: included, as BASELINE configs[2] says \"WLS solve\")")
+    ap.add_argument("--no-null-pivots", action="store_true",
+                    help="plain Householder column steps for the dependent columns too (figh_tsqr_null_pivot_tol = 0)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="cfg2: K1 and the level-0 TSQR as two launches (W written, then read back) instead of the fused "
                          "launch figh_regressor_tsqr_fused (default: fused from the second pass on; config.fused says which)")
@@ -254,7 +256,8 @@ def main():
     pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
                                   chunk_samples=chunk, placement_trials=args.placement_trials,
                                   structural_zeros=args.structural_zeros,
-                                  w_layout="dense" if args.w_layout == "dense" else "block-compact", fuse=not args.no_fuse)
+                                  w_layout="dense" if args.w_layout == "dense" else "block-compact", fuse=not args.no_fuse,
+                                  null_pivots=not args.no_null_pivots)
     _lib.synchronize()
     t_h2d = time.perf_counter()
     pipe.set_samples(q, v, a)
@@ -484,6 +487,10 @@ def main():
                              % (8e-9 * pipe.N * float(pipe._compact[1].sum()), 8e-9 * pipe.W.rows * pipe.W.ld))
                 if getattr(pipe, "_compact", None) is not None else "dense",
                 "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
+                "null_pivots": ("on: columns null to tol_qr / 64 skip their column steps (figh_tsqr_null_pivot_tol)"
+                                if pipe.null_pivots else "off"),
+                "pivots": {"dependent_max": float(np.max(np.delete(out["absdiagR"], out["idx_base"]), initial=0.0)),
+                           "base_min": float(np.min(np.asarray(out["absdiagR"])[out["idx_base"]])), "tol_qr": pipe.tol_qr},
                 "fused": ("K1 + level-0 TSQR in one launch (figh_regressor_tsqr_fused), %d of the %d timed and warm-up passes"
                           % (pipe.fused_passes, args.steps + args.warmup + 2)) if pipe.fused_passes else
                          "no (two launches: W written by K1, read back by the TSQR)",

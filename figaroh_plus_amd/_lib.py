@@ -33,6 +33,7 @@ SIGNATURES = {
     "figh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "figh_device_set": (C.c_int, [C.c_int]),
     "figh_host_wait_mode": (C.c_int, [C.c_int]),
+    "figh_tsqr_null_pivot_tol": (C.c_int, [C.c_double]),
     "figh_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "figh_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "figh_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
@@ -201,6 +202,35 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+_null_tol = 0.0
+
+
+def tsqr_null_pivot_tol(tol):
+    """Threshold of the null-pivot rule of the TSQR kernels (include/figh.h); 0 = exact zeros only.  Returns the previous one."""
+    global _null_tol
+    check(load().figh_tsqr_null_pivot_tol(float(tol)))
+    prev, _null_tol = _null_tol, float(tol)
+    return prev
+
+
+class null_pivots:
+    """``with null_pivots(tol_qr): ...`` -- the TSQR launches inside run with the null-pivot rule at tol_qr / 64: a column
+    that is going to be classified as dependent (|R_kk| <= tol_qr, qrdecomposition.py:215-221) by a margin of 64 costs a
+    norm per tile instead of a column step."""
+
+    def __init__(self, tol_qr):  # None: leave the process-wide setting alone
+        self.tol = None if tol_qr is None else max(float(tol_qr), 0.0) / 64.0
+
+    def __enter__(self):
+        self.prev = None if self.tol is None else tsqr_null_pivot_tol(self.tol)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            tsqr_null_pivot_tol(self.prev)
+        return False
 
 
 def profile_enable(on=True, level=2):

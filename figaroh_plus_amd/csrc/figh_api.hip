@@ -43,6 +43,9 @@ void set_error(const std::string &msg) { g_error = msg; }
 hipStream_t stream() { return g_stream; }
 
 static bool g_blocking_wait = false;
+static double g_null_pivot_sq = 0.0;
+
+double null_pivot_sq() { return g_null_pivot_sq; }
 
 int ensure_device() {
     if (g_ready) return FIGH_OK;
@@ -176,6 +179,12 @@ int figh_device_pci_bus_id(int device, char *out, int out_len) {
         set_error(std::string("hipDeviceGetPCIBusId: ") + hipGetErrorString(e));
         return FIGH_ERR_NO_DEVICE;
     }
+    return FIGH_OK;
+}
+
+int figh_tsqr_null_pivot_tol(double tol) {
+    FIGH_REQUIRE(tol >= 0.0 && tol < 1.0, "figh_tsqr_null_pivot_tol: 0 <= tol < 1");
+    g_null_pivot_sq = tol * tol;
     return FIGH_OK;
 }
 

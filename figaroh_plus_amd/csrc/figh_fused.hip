@@ -109,7 +109,7 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
     const ChainParams<NJ> P, const int flags, const long N, const double *__restrict__ q, const double *__restrict__ v,
     const double *__restrict__ a, double *__restrict__ W, const double *__restrict__ tau, const int *__restrict__ col_idx,
     const int n, const int nc, double *__restrict__ colsq_part, double *__restrict__ Rws, const int ncons,
-    const int tri_doubles) {
+    const int tri_doubles, const double null2) {
     using G = FusedGeom<NJ>;
     constexpr int NC = G::NC, LDT = G::LDT, CH = G::CH;
     constexpr int NCC = 4, NRC = 4, RPL = 16;
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
     S.lane_c = lane & 15;
     S.lane_g = lane >> 4;
     S.nc = nc;
+    S.null2 = null2;
 #pragma unroll
     for (int sl = 0; sl < 4 * NCC; ++sl) S.Rq[sl] = 0.0;
     // per-lane column sources inside an LDS tile: kept column col_idx[col] for col < n, the tau slot (column NC) for
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
     const long long prof_start = __builtin_readcyclecounter();
 #endif
     int pref = c_id & 1;  // the buffer this wave looks at first
+    int absorbed = 0;     // tiles this wave has factored
     for (;;) {
         FUSED_TICK(c0);
         // claim the next announced tile of either buffer (lane 0 decides, the wave follows): -1 = everything is claimed
@@ -529,6 +531,8 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
         lds_post(&ctrl->taken, tpick + 1);
         FUSED_TICK(c2);
         FUSED_ADD(9, c2 - c1);
+        S.null2 = absorbed * 64 < nc + 8 ? 0.0 : null2;  // (null pivots once the triangle is of full height: see tsqr2_level0_body)
+        ++absorbed;
         tsqr2_panels<0, NCC, NRC, false, true>(S, first_nz, [](auto) {});
         FUSED_TICK(c3);
         FUSED_ADD(10, c3 - c2);
@@ -628,7 +632,7 @@ static int launch_fused(const figh_model_s *m, int flags, long N, const double *
     {
         ProfileScope scope("fused_chain_tsqr", true);
         FIGH_LAUNCH_TIMED((fused_chain_tsqr_kernel<NJ>), dim3((unsigned)grid), dim3(64 * (G::NPROD + ncons)), lds, P, flags, N, q,
-                          v, a, W, tau, d_kept, n, nc, part, Rws, ncons, (int)tri);
+                          v, a, W, tau, d_kept, n, nc, part, Rws, ncons, (int)tri, null_pivot_sq());
     }
     hipLaunchKernelGGL(fused_reduce_partials_kernel, dim3(G::NC), dim3(256), 0, stream(), part, (int)(grid * G::NPROD),
                        G::NC, d_colsq);

@@ -41,6 +41,7 @@ struct figh_model_s {
 namespace figh {
 
 void set_error(const std::string &msg);
+double null_pivot_sq();  // square of figh_tsqr_null_pivot_tol (0: exact zeros only)
 hipStream_t stream();
 int ensure_device();
 

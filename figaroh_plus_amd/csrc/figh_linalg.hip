@@ -35,9 +35,9 @@ template <int NCC, int NRC, bool LDSRED>
 __global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
     const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
     const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
-    double *__restrict__ Rws, const int nc, const int *__restrict__ tile_first) {
+    double *__restrict__ Rws, const int nc, const int *__restrict__ tile_first, const double null2) {
     tsqr2_level0_body<NCC, NRC, LDSRED>(W, rows, ldw, col_idx, n, tau, blkw, rows_per_blk, Rws, nc, tile_first,
-                                        (long)blockIdx.x, (long)gridDim.x);
+                                        (long)blockIdx.x, (long)gridDim.x, null2);
 }
 
 
@@ -471,10 +471,10 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
     dim3 grid((unsigned)nw), block(64);
     if (nc <= 64)
         FIGH_LAUNCH_TIMED((tsqr2_kernel<4, 4, true>), grid, block, tsqr2_lds_bytes(4, nc), W, rows, ldw, col_idx, n, tau,
-                          d_blkw, rows_per_blk, Rws_out, nc, th);
+                          d_blkw, rows_per_blk, Rws_out, nc, th, null_pivot_sq());
     else
         FIGH_LAUNCH_TIMED((tsqr2_kernel<5, 4, false>), grid, block, tsqr2_lds_bytes(5, nc), W, rows, ldw, col_idx, n, tau,
-                          d_blkw, rows_per_blk, Rws_out, nc, th);
+                          d_blkw, rows_per_blk, Rws_out, nc, th, null_pivot_sq());
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }

@@ -30,11 +30,11 @@ namespace figh {
 // into retired registers, 8-way interleaved tile order) on the job's matrix; `zeros` = a structure hint of all zeros.
 __global__ __launch_bounds__(64, 2) void tsqr2_group_kernel(const Tsqr2Job *__restrict__ jobs,
                                                             const int *__restrict__ job_of_wave,
-                                                            const int *__restrict__ zeros) {
+                                                            const int *__restrict__ zeros, const double null2) {
     const int jid = __builtin_amdgcn_readfirstlane(job_of_wave[blockIdx.x]);
     const Tsqr2Job *J = jobs + jid;
     tsqr2_level0_body<4, 4, true>(J->W, J->rows, J->ldw, J->col_idx, J->n, J->tau, (const double *)nullptr, 1L, J->tri, J->nc,
-                                  zeros, (long)blockIdx.x - J->wave0, (long)J->nwaves);
+                                  zeros, (long)blockIdx.x - J->wave0, (long)J->nwaves, null2);
 }
 
 // ------------------------------------------------------------------------------------------------ merge levels
@@ -188,7 +188,7 @@ int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cu
     {
         ProfileScope scope("tsqr_group");
         hipLaunchKernelGGL(tsqr2_group_kernel, dim3((unsigned)job_of_wave.size()), dim3(64), lds, stream(), d_jobs, d_maps,
-                           (const int *)zeros);
+                           (const int *)zeros, null_pivot_sq());
         for (int l = 0; l < 3; ++l)
             if (!job_of_wg[l].empty())
                 hipLaunchKernelGGL(tsqr_coop_group_kernel, dim3((unsigned)job_of_wg[l].size()), dim3(512), 0, stream(), d_jobs,

@@ -32,6 +32,7 @@ struct Tsqr2State {
     int lane_c;   // lane & 15
     int lane_g;   // lane >> 4
     int nc;
+    double null2;  // null-pivot rule (figh_tsqr_null_pivot_tol): threshold squared, 0 = only exact zeros
 };
 
 // doubles of LDS in front of row 0 of panel P in the packed triangle (LCH chunks per row of panel 0)
@@ -109,32 +110,55 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
     }
     const double inv = copysign(ri, alpha);
     const double tfac = dsum * rs;
+    // NULL PIVOT (dlarfg's H = I rule with a threshold, figh_tsqr_null_pivot_tol): the column is zero to working accuracy
+    // at and below the diagonal -- a linearly dependent column of the regressor, whose residual is rounding noise in every
+    // tile.  Its norm moves into R_kk (which therefore keeps the running residual norm of the column: the test is on
+    // alpha^2 + sigma, so at most null2 of a column's energy is ever folded), the column leaves the tile, and no reflector
+    // is formed: no trailing dot products, no trailing updates.  q2 is the same number in every lane.
+    const bool live = __builtin_amdgcn_ballot_w64(q2 > S.null2) != 0;
+    if (live) {
 #pragma unroll
-    for (int cc = 1; cc < LIVE; ++cc) {
-        double s0 = 0.0, s1 = 0.0;
+        for (int cc = 1; cc < LIVE; ++cc) {
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < NR; i += 2) {
-            fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
-            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
+            for (int i = 0; i < NR; i += 2) {
+                fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
+                fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
+            }
+            d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
         }
-        d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
+        // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
+        //   - the pivot lane itself gets w = (alpha + sigma inv) tfac = alpha - beta, hence R_kk = alpha - w = beta and
+        //     c = w inv = 1: its tile entries x - 1 x vanish (the finished column leaves the tile);
+        //   - finished lane-columns (c < KK) and padding hold zeros (up to rounding residues that are never read as
+        //     results), so their w is zero by itself.
+        // Trailing chunks first, the pivot chunk last: its own update is the only write to the DPP source registers.
+#pragma unroll
+        for (int cc = LIVE - 1; cc >= 1; --cc) {
+            const double wj = (Rk[cc] + d[cc] * inv) * tfac;
+            const double ncj = -wj * inv;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) fmac_bcast<KK>(S.T[P + cc][i], S.T[P][i], ncj);
+            if (RLAST && cc == LIVE - 1) {
+                if (S.lane_g == g0) S.Rq[slot] = Rk[cc] - wj;
+            } else {
+                if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = Rk[cc] - wj;
+            }
+        }
     }
-    // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
-    //   - the pivot lane itself gets w = (alpha + sigma inv) tfac = alpha - beta, hence R_kk = alpha - w = beta and
-    //     c = w inv = 1: its tile entries x - 1 x vanish (the finished column leaves the tile);
-    //   - finished lane-columns (c < KK) and padding hold zeros (up to rounding residues that are never read as
-    //     results), so their w is zero by itself.
-    // Trailing chunks first, the pivot chunk last: its own update is the only write to the DPP source registers.
+    {
+        // the pivot chunk; null pivot: w = R_kk - sign(R_kk) s and c = 1 in the pivot lane, zero in the others
+        const double wl = (Rk[0] + d[0] * inv) * tfac;
+        const double wn = S.lane_c == KK ? alpha - copysign(q2 * rs, alpha) : 0.0;
+        const double wj = live ? wl : wn;
+        const double nn = S.lane_c == KK ? -1.0 : 0.0;
+        const double ncj = live ? -wl * inv : nn;
 #pragma unroll
-    for (int cc = LIVE - 1; cc >= 0; --cc) {
-        const double wj = (Rk[cc] + d[cc] * inv) * tfac;
-        const double ncj = -wj * inv;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) fmac_bcast<KK>(S.T[P + cc][i], S.T[P][i], ncj);
-        if (RLAST && cc == LIVE - 1) {
-            if (S.lane_g == g0) S.Rq[slot] = Rk[cc] - wj;
+        for (int i = 0; i < NR; ++i) fmac_bcast<KK>(S.T[P][i], S.T[P][i], ncj);
+        if (RLAST && LIVE == 1) {
+            if (S.lane_g == g0) S.Rq[slot] = Rk[0] - wj;
         } else {
-            if (S.lane_g == 0) S.Rl[rowoff + 16 * cc + S.lane_c] = Rk[cc] - wj;
+            if (S.lane_g == 0) S.Rl[rowoff + S.lane_c] = Rk[0] - wj;
         }
     }
 }

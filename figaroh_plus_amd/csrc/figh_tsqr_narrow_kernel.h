@@ -13,7 +13,8 @@ template <int NCC, int NRC, bool LDSRED>
 __device__ __forceinline__ void tsqr2_level0_body(
     const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
     const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
-    double *__restrict__ Rws, const int nc, const int *__restrict__ tile_first, const long wave, const long tstep) {
+    double *__restrict__ Rws, const int nc, const int *__restrict__ tile_first, const long wave, const long tstep,
+    const double null2) {
     // tile_first[t] (always a valid array; zeros without a structure hint, figh_tsqr_structured): the first kept column
     // that can hold a non-zero in tile t.  Lanes in front of it are not read at all (their registers are zeroed, the
     // loads run under a narrower EXEC mask): in the joint-major regressor of a chain, row block j only involves the
@@ -41,6 +42,7 @@ __device__ __forceinline__ void tsqr2_level0_body(
     S.lane_c = lane & 15;
     S.lane_g = lane >> 4;
     S.nc = nc;
+    S.null2 = null2;
     // per-lane column sources: W[:, col_idx[col]] for col < n; tau is column n = nc - 1, i.e. lane-column 15 of the
     // last chunk; everything else (padding) is a dead lane-column whose registers stay exactly zero for the whole
     // kernel (zero data, zero R row entry => w_j = c_j = 0 in every step), so they are zeroed once and never loaded.
@@ -90,6 +92,7 @@ __device__ __forceinline__ void tsqr2_level0_body(
     };
 
     bool prefetched = false;
+    int absorbed = 0;  // tiles this wave has factored
     // The SIMD arbiter favours the older of its two resident waves, which then finishes ~25 % earlier and leaves
     // the younger one running alone (at a single wave's issue efficiency) for the rest of the kernel.  The two
     // halves of the grid therefore alternate their issue priority per tile, in antiphase, so that both waves of a
@@ -180,6 +183,12 @@ __device__ __forceinline__ void tsqr2_level0_body(
         if (nzlo) first_nz = __ffsll((long long)nzlo) - 1;
         else if (nzhi) first_nz = 64 + __ffs((int)nzhi) - 1;
 
+        // null pivots only once the triangle is of full height: a tile that exhausts the rank of what has been absorbed so
+        // far forms its last reflectors from small residuals, which leaves noise of 1e-11 (instead of 1e-13) in the columns
+        // behind them -- harmless for a Householder step (the garbage reflectors of the dependent columns annihilate it),
+        // but a null pivot would keep it as its |R_kk| (tools/null_pivot_noise.py)
+        S.null2 = absorbed * M < nc + M / 8 ? 0.0 : null2;
+        ++absorbed;
         tsqr2_panels<0, NCC, NRC, LDSRED>(S, first_nz, [&](auto P) {
             if constexpr (decltype(P)::value < NCC - 1) {
                 if (next_fast) load_chunk(P, r0n, fposn);

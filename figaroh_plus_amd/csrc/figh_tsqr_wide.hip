@@ -49,7 +49,7 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
         FIGH_LAUNCH_TIMED((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
                                           decltype(WPE)::value, decltype(LDSC)::value, 0>),
                           dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, W, rows, ldw, col_idx, n, tau, d_blkw,
-                          rows_per_blk, Rblk, Rws_out, nc, prof, 0L, 0);
+                          rows_per_blk, Rblk, Rws_out, nc, prof, 0L, 0, null_pivot_sq());
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");

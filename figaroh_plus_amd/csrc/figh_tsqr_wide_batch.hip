@@ -20,7 +20,7 @@ int launch_tsqr_wide_batch(const double *W, long ldw, const int *col_idx, int n,
                                            decltype(WPE)::value, decltype(LDSC)::value, 2>),
                            dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, stream(), W, n_per, ldw, col_idx, n,
                            (const double *)nullptr, (const double *)nullptr, seg_stride, Rblk, Rws_out, nc,
-                           (long long *)nullptr, wgs, rps);
+                           (long long *)nullptr, wgs, rps, null_pivot_sq());
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");
@@ -42,7 +42,7 @@ int launch_tsqr_wide_chain(const double *W, long rows, long ldw, const int *col_
         FIGH_LAUNCH_TIMED((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
                                           decltype(WPE)::value, decltype(LDSC)::value, 3>),
                           dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, W, rows, ldw, col_idx, n, tau, d_blkw,
-                          rows_per_blk, Rblk, Rws_out, nc, (long long *)nullptr, 0L, 0);
+                          rows_per_blk, Rblk, Rws_out, nc, (long long *)nullptr, 0L, 0, null_pivot_sq());
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");

@@ -106,7 +106,7 @@ struct TColumn<M1, M1> {
 template <int KK, int RPL>
 __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, double *__restrict__ Rl,
                                               double *__restrict__ Tl, double *__restrict__ red, const int lane,
-                                              const int c) {
+                                              const int c, const double null2) {
     double rk = Rl[KK * 16 + c];  // row KK of the diagonal block: requested before the dot products
     constexpr int KH = KK < 8 ? KK : 8;
     double tr[8];
@@ -123,7 +123,12 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
     asm volatile("" : "+v"(rk));
     const double sigma = row_bcast<KK>(d);
     const double alpha = row_bcast<KK>(rk);
-    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
+    // column zero below the triangle: H = I (dlarfg) -- or NULL PIVOT (figh_tsqr_null_pivot_tol, see tsqr2_step in
+    // figh_tsqr_narrow.h): zero to working accuracy at and below the diagonal.  H = I as well: tau = 0 (column KK of T stays
+    // zero), v = 0 (myinv stays zero: a zero column of V and of every later Gram entry), no update; the column's entries stay
+    // in X untouched and wy_factor_panel folds their norm into R_kk after the last step.  A third of the dependent chain of a
+    // step instead of all of it.
+    if (__builtin_amdgcn_ballot_w64(sigma != 0.0 && fma(alpha, alpha, sigma) > null2) == 0) return;
     // (x_m^T x_KK) inv_m in lane-column m < KK, zero elsewhere (myinv is still zero for the columns not yet factored)
     double vg = d * myinv;
     asm volatile("s_nop 1" : "+v"(vg));  // VALU write -> DPP read of vg below: 2 wait states
@@ -158,7 +163,7 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
 template <int RPL>
 __device__ __forceinline__ void wy_factor_panel(double (&X)[RPL], double *__restrict__ Rl, double *__restrict__ red,
                                                 double *__restrict__ Vl, double *__restrict__ Tl, const int lane,
-                                                const int c, const int g) {
+                                                const int c, const int g, const double null2) {
     double myinv = 0.0;
 #pragma unroll
     for (int e = lane; e < 16 * kLdt; e += 64) Tl[e] = 0.0;
@@ -171,22 +176,41 @@ __device__ __forceinline__ void wy_factor_panel(double (&X)[RPL], double *__rest
     for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(X[i]));
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    wy_panel_step<0, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<1, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<2, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<3, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<4, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<5, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<6, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<7, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<8, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<9, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<10, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<11, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<12, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<13, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<14, RPL>(X, myinv, Rl, Tl, red, lane, c);
-    wy_panel_step<15, RPL>(X, myinv, Rl, Tl, red, lane, c);
+    wy_panel_step<0, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<1, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<2, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<3, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<4, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<5, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<6, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<7, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<8, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<9, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<10, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<11, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<12, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<13, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<14, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<15, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    // null pivots: the norm of what the column still holds below the triangle moves into R_kk (all sixteen lane-columns at
+    // once; nothing to do for columns that formed a reflector or are exactly zero)
+    if (null2 > 0.0) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; i += 2) {
+            s0 = fma(X[i], X[i], s0);
+            s1 = fma(X[i + 1], X[i + 1], s1);
+        }
+        const double sc = FIGH_WY_REDUCE(red, lane, s0 + s1);
+        if (lane < 16 && myinv == 0.0 && sc != 0.0) {
+            const double r = Rl[c * 16 + c];
+            const double q2 = fma(r, r, sc);
+            double rs = __builtin_amdgcn_rsq(q2);
+            const double e = fma(-(q2 * rs), rs, 1.0);
+            rs = fma(rs, fma(e, 0.375, 0.5) * e, rs);
+            Rl[c * 16 + c] = copysign(q2 * rs, r);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RPL; ++i) Vl[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c] = X[i] * myinv;
 }
@@ -325,7 +349,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                                                                const double *__restrict__ blkw, const long rows_per_blk,
                                                                double *__restrict__ Rblk, double *__restrict__ Rout,
                                                                const int nc, long long *__restrict__ prof,
-                                                               const long pair_count, const int aux) {
+                                                               const long pair_count, const int aux, const double null2_) {
     // MODE 0: level 0 (rows of one tall matrix, tiles dealt round-robin).  MODE 1 = PAIR, MODE 2 = BATCH, below.
     constexpr bool PAIR = MODE == 1, BATCH = MODE == 2;
     // PAIR (pair-merge mode).  W_ is a stack of pair_count compact nc x nc triangles (ldw == nc); workgroup b
@@ -504,7 +528,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     int parity = 0;
     int front = wave;       // chunk held by F; Q[j] holds front + NW (j + 1)
     bool prefetched = false;  // the queue already holds the coming tile (every chunk retires once per tile)
+    // null pivots (figh_tsqr_null_pivot_tol) only once the workgroup's triangle is of full height (level 0: it starts
+    // empty): see tsqr2_level0_body, figh_tsqr_narrow_kernel.h
+    int young = (PAIR || CHAIN) ? 0 : (nc + M / 8 + M - 1) / M;
     for (long t = tile0; t < ntiles; t += tstep, parity ^= 1) {
+        const double null2 = young > 0 ? 0.0 : null2_;
+        young -= young > 0 ? 1 : 0;
         long r0, r0n, left = 0, leftn = 0;
         bool next_full;  // the workgroup has another tile (full or ragged: the descriptor zero-fills)
         if constexpr (BATCH) {
@@ -613,7 +642,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                 }
                 FIGH_WY_WAVE_SYNC();
                 FIGH_PROF_ADD(8);
-                wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
+                wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g, null2);
                 FIGH_WY_WAVE_SYNC();
                 FIGH_PROF_ADD(9);
 #pragma unroll
@@ -685,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
                     }
                     FIGH_WY_WAVE_SYNC();
                     FIGH_PROF_ADD(7);
-                    wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g);
+                    wy_factor_panel<RPL>(X, Rl, red, Vn, Vn + M * kLdv, lane, c, g, null2);
                     FIGH_WY_WAVE_SYNC();
                     FIGH_PROF_ADD(4);
 #pragma unroll

@@ -51,7 +51,7 @@ int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_
                                            decltype(WPE)::value, decltype(LDSC)::value, 1>),
                            dim3((unsigned)nwg), dim3(64 * decltype(NW)::value), 0, stream(), stack, (long)nc, (long)nc,
                            (const int *)nullptr, nc, (const double *)nullptr, (const double *)nullptr, 1L, Rblk, Rws_out,
-                           nc, (long long *)nullptr, count, 0);
+                           nc, (long long *)nullptr, count, 0, null_pivot_sq());
     };
     // More pairs than CUs (the stacked triangles of a streamed run: 20 chunks x 512 for the human model): the level is
     // throughput-bound, and the level-0 geometry -- four waves, two workgroups = two chains per CU -- absorbs twice as
@@ -78,7 +78,8 @@ int launch_tsqr_wide_single(const double *W, long rows, long ldw, const int *col
         hipLaunchKernelGGL((tsqr_wy_kernel<decltype(NW)::value, decltype(CPW)::value, decltype(NRC)::value,
                                            decltype(WPE)::value, decltype(LDSC)::value, 0>),
                            dim3(1), dim3(64 * decltype(NW)::value), 0, stream(), W, rows, ldw, col_idx, n,
-                           (const double *)nullptr, (const double *)nullptr, 1L, Rblk, R_out, nc, (long long *)nullptr, 0L, 0);
+                           (const double *)nullptr, (const double *)nullptr, 1L, Rblk, R_out, nc, (long long *)nullptr, 0L, 0,
+                           null_pivot_sq());
     });
     if (!ok) {
         set_error("figh_tsqr: no wide-kernel geometry for this column count");

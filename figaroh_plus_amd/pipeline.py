@@ -80,7 +80,7 @@ def _solve_upper(R1, B):
 
 class IdentificationPipeline:
     def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
-                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass", w_layout="dense", fuse=True):
+                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass", w_layout="dense", fuse=True, null_pivots=True):
         """``chunk_samples``: when the stacked regressor of all N samples does not fit HBM (human model at 1e7
         samples: 269 GB) the samples are processed in chunks of this size -- pass 1 accumulates diag(W^T W), pass 2
         rebuilds each chunk's W (recomputing is far cheaper than storing), factors it and stacks the triangles,
@@ -91,6 +91,7 @@ class IdentificationPipeline:
         # while it is still in LDS, W is written but not read back.  The list is verified against the norms the pass produces;
         # a pass whose kept set changed falls back to the two launches below (and learns the new list).
         self.fuse = bool(fuse)
+        self.null_pivots = bool(null_pivots)
         self._fused_kept = None
         self.fused_passes = 0
         # structural_zeros = "once" (opt-in, joint-torque regressor of a tree kept in HBM): W is zero-filled when it is
@@ -281,14 +282,17 @@ class IdentificationPipeline:
         ends in the rank-revealing level, and one copy brings back [column norms | selection | triangle rows].  The count
         is verified against the device's own afterwards; the first pass (count unknown) and a pass whose count changed
         repeat the solve with the right one."""
-        if self._chunked():
+        # (null_pivots: the dependent columns of the regressor -- |R_kk| <= tol_qr by a margin of 64 -- cost a norm per tile
+        # instead of a column step in every TSQR launch of the pass, include/figh.h: figh_tsqr_null_pivot_tol)
+        with _lib.null_pivots(self.tol_qr if self.null_pivots else None):
+            if self._chunked():
+                if wls:
+                    raise NotImplementedError("wls=True needs the regressor resident in HBM (no chunk_samples)")
+                return self._run_chunked(strings)
+            out = self._run_resident(strings, wls)
             if wls:
-                raise NotImplementedError("wls=True needs the regressor resident in HBM (no chunk_samples)")
-            return self._run_chunked(strings)
-        out = self._run_resident(strings, wls)
-        if wls:
-            self._wls(out)
-        return out
+                self._wls(out)
+            return out
 
     def _run_resident(self, strings, wls):
         ex = self.exchange

@@ -19,11 +19,13 @@ from ..device import GpuMatrix, index_to_device, to_device, vector_to_device
 TOL_QR = 1e-8
 
 
-def rfactor(W, tau=None, col_idx=None, block_weight=None):
+def rfactor(W, tau=None, col_idx=None, block_weight=None, tol_qr=None):
     """Upper-triangular factor of ``[W[:, col_idx], tau]`` (rows scaled per block by ``block_weight``).
 
     Returns an (nc, nc) array, nc = n (+1 with tau); with tau the last column holds Q^T tau and,
-    in its last entry, the residual norm of the least-squares problem.
+    in its last entry, the residual norm of the least-squares problem.  ``tol_qr``: the caller is going to
+    classify |R_kk| <= tol_qr as dependent -- columns that are null to tol_qr / 64 skip their column steps
+    (``_lib.null_pivots``); None: plain Householder.
     """
     Wd, _ = to_device(W)
     if Wd.rows == 0:
@@ -42,7 +44,8 @@ def rfactor(W, tau=None, col_idx=None, block_weight=None):
         d_tau = vector_to_device(tau)
     nc = n + (1 if tau is not None else 0)
     d_R = _lib.DeviceArray((nc * nc,), np.float64)
-    _lib.tsqr(Wd.buf, Wd.rows, Wd.ld, d_idx, n, d_tau, block_weight, d_R)
+    with _lib.null_pivots(tol_qr):
+        _lib.tsqr(Wd.buf, Wd.rows, Wd.ld, d_idx, n, d_tau, block_weight, d_R)
     return np.triu(d_R.to_host().reshape(nc, nc))
 
 
@@ -87,7 +90,7 @@ def _base_columns(Wd, idx, keep_on_device=False):
 @host_tail
 def get_baseIndex(W_e, params_r, tol_qr=TOL_QR):
     """Indices of the linearly independent columns (qrdecomposition.py:274-296)."""
-    R = rfactor(W_e)
+    R = rfactor(W_e, tol_qr=tol_qr)
     idx_base, _ = _select(np.diag(R), params_r, tol_qr)
     return tuple(idx_base)
 
@@ -102,7 +105,7 @@ def build_baseRegressor(W_e, idx_base):
 def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
     """(W_b, params_base, idx_base) -- qrdecomposition.py:190-271."""
     Wd, on_dev = to_device(W_e)
-    R = rfactor(Wd)
+    R = rfactor(Wd, tol_qr=tol_qr)
     idx_base, idx_regroup = _select(np.diag(R), params_r, tol_qr)
     R1, R2, _ = _regroup(R, idx_base, idx_regroup, False)
     with single_threaded_blas():  # n x n host work: see _host.py
@@ -117,7 +120,7 @@ def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
 def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR):
     """(W_b, base_parameters, params_base, phi_b[, phi_std]) -- qrdecomposition.py:89-187."""
     Wd, on_dev = to_device(W_e)
-    R = rfactor(Wd, tau=tau)
+    R = rfactor(Wd, tau=tau, tol_qr=tol_qr)
     n = len(params_r)
     assert R.shape[0] == n + 1, "params_r does not have same length with R"
     idx_base, idx_regroup = _select(np.diag(R)[:n], params_r, tol_qr)

@@ -76,6 +76,17 @@ int figh_device_set(int device);
  * process that exhausts it is frozen until the next 100 ms accounting period.  Call before figh_device_set / any
  * device call.  No reference analogue (the reference has no device). */
 int figh_host_wait_mode(int blocking);
+/* Null-pivot rule of the Householder TSQR kernels (figh_tsqr*, figh_regressor_tsqr*): a pivot column whose norm at and below
+ * the diagonal is <= tol -- sqrt(R_kk^2 + |x|^2) <= tol for the tile's part x of the column -- gets H = I (LAPACK dlarfg's
+ * rule for an exactly zero x, with a threshold): its norm is folded into R_kk, the column leaves the tile, no reflector
+ * is formed and no trailing update is made.  R_kk therefore carries the running residual norm of the column and the test
+ * includes it, so that over ALL the rows of a matrix at most tol of a column's norm is ever folded: R is the exact R
+ * factor of W + E with |E[:, k]| <= tol for such columns, E = 0 elsewhere.  The linearly dependent columns of a regressor
+ * (qrdecomposition.py:208-221: |R_kk| <= tol_qr, 27 % of the kept columns of UR10 and 29 % of TALOS) are such columns in
+ * every tile -- their residual is rounding noise -- and cost a norm instead of a column step.  tol = 0 (the default):
+ * exact zeros only.  The pipeline and the qrdecomposition mirrors set tol_qr / 64.  Process-wide, takes effect at the
+ * next launch. */
+int figh_tsqr_null_pivot_tol(double tol);
 /* PCI bus id ("0000:c1:00.0") of HIP device `device`: the physical device a rank drives, whatever logical index the
  * launcher's HIP_VISIBLE_DEVICES left it with (figaroh_plus_amd/dist.py: two ranks on one GPU cannot form an RCCL
  * communicator).  Creates no context.  No reference analogue. */

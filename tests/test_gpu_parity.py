@@ -882,6 +882,87 @@ def test_tsqr_shapes_against_lapack(lib, n, rows):
         assert np.abs(Ra.T @ Ra - Ga).max() <= 1e-12 * np.abs(Ga).max()
 
 
+def _rank_deficient(rng, rows, n, ndep):
+    """rows x n, ndep of the columns (at random places, never the first) exact combinations of columns in front of them"""
+    A = rng.standard_normal((rows, n)) * rng.uniform(0.5, 20.0, n)
+    dep = np.sort(rng.choice(np.arange(1, n), ndep, replace=False))
+    for j in dep:
+        src = [k for k in range(j) if k not in set(dep.tolist())]
+        pick = rng.choice(src, min(3, len(src)), replace=False)
+        A[:, j] = A[:, pick] @ rng.uniform(-2.0, 2.0, len(pick))
+    return A, dep
+
+
+@pytest.mark.parametrize("n,ndep", [(50, 13), (64, 20), (80, 9), (96, 30), (191, 27), (241, 60), (331, 96), (400, 40)])
+@pytest.mark.parametrize("rows", [4096, 50011])
+def test_null_pivot_rule_on_rank_deficient_matrices(lib, n, ndep, rows):
+    """figh_tsqr_null_pivot_tol (include/figh.h): dependent columns -- qrdecomposition.py:208-221's |R_kk| <= tol_qr -- skip
+    their column steps.  Every kernel family.  With and without the rule: the same base set, R^T R = A^T A to rounding,
+    |R_kk| of the dependent columns below tol_qr and equal in size, the base solution identical."""
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.tools.qrdecomposition import rfactor
+    rng = np.random.default_rng(77 * n + rows)
+    A, dep = _rank_deficient(rng, rows, n, ndep)
+    t = A @ rng.standard_normal(n) + 0.1 * rng.standard_normal(rows)
+    G = np.c_[A, t].T @ np.c_[A, t]
+    out = {}
+    try:
+        for tol in (0.0, 1e-8 / 64):
+            _lib.tsqr_null_pivot_tol(tol)
+            out[tol] = rfactor(A, tau=t)
+    finally:
+        _lib.tsqr_null_pivot_tol(0.0)
+    base = np.setdiff1d(np.arange(n), dep)
+    phi = {}
+    for tol, R in out.items():
+        assert np.array_equal(R, np.triu(R))
+        assert np.abs(R.T @ R - G).max() <= 1e-12 * np.abs(G).max()
+        d = np.abs(np.diag(R))[:n]
+        assert np.array_equal(np.flatnonzero(d > 1e-8), base)
+        assert d[dep].max() <= 5e-9
+        Rb = np.linalg.qr(R[:, list(base) + [n]], mode="r")
+        phi[tol] = np.linalg.solve(Rb[:len(base), :len(base)], Rb[:len(base), -1])
+    assert np.abs(phi[0.0] - phi[1e-8 / 64]).max() <= 1e-10 * np.abs(phi[0.0]).max()
+    ref = np.linalg.lstsq(A[:, base], t, rcond=None)[0]
+    assert np.abs(phi[1e-8 / 64] - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n", [50, 96, 241, 331])
+def test_null_pivot_rule_column_that_becomes_independent_late(lib, n):
+    """A column that is an exact combination of earlier ones in the first 90 % of the rows and not in the rest (a joint that
+    only starts to move late in the trajectory): null in the early tiles, a regular pivot from the first tile in which it
+    is not.  Nothing of it may be lost: R^T R = A^T A, the column is a base column, same solution as LAPACK."""
+    from figaroh_plus_amd import _lib
+    from figaroh_plus_amd.tools.qrdecomposition import rfactor
+    rows = 40000
+    rng = np.random.default_rng(5 * n)
+    A, dep = _rank_deficient(rng, rows, n, max(3, n // 6))
+    late = int(dep[len(dep) // 2])
+    A[36000:, late] += rng.standard_normal(rows - 36000)
+    tiny = int(dep[0])                      # ... and one that differs from its combination by 1e-10 per entry throughout:
+    A[:, tiny] += 1e-10 * rng.standard_normal(rows)   # |R_kk| ~ 2e-8 > tol_qr, folded in no tile but the first few
+    t = A @ rng.standard_normal(n) + 0.1 * rng.standard_normal(rows)
+    G = np.c_[A, t].T @ np.c_[A, t]
+    try:
+        _lib.tsqr_null_pivot_tol(1e-8 / 64)
+        R = rfactor(A, tau=t)
+        _lib.tsqr_null_pivot_tol(0.0)
+        R0 = rfactor(A, tau=t)
+    finally:
+        _lib.tsqr_null_pivot_tol(0.0)
+    assert np.abs(R.T @ R - G).max() <= 1e-12 * np.abs(G).max()
+    d, d0 = np.abs(np.diag(R))[:n], np.abs(np.diag(R0))[:n]
+    base = np.flatnonzero(d > 1e-8)
+    assert np.array_equal(base, np.flatnonzero(d0 > 1e-8))
+    assert late in base and tiny in base and len(base) == n - len(dep) + 2
+    assert abs(d[tiny] - d0[tiny]) <= 0.02 * d0[tiny]
+    ref = np.linalg.lstsq(A[:, np.setdiff1d(base, [tiny])], t, rcond=None)[0]
+    keep = [int(k) for k in base if k != tiny]
+    Rb = np.linalg.qr(R[:, keep + [n]], mode="r")
+    phi = np.linalg.solve(Rb[:len(keep), :len(keep)], Rb[:len(keep), -1])
+    assert np.abs(phi - ref).max() <= 1e-7 * np.abs(ref).max()
+
+
 def test_regressor_leading_dimension_and_colsq(lib, golden_ur10):
     """ldw > ncols (padded rows, scalar store path) and the fused column norms against figh_colsq."""
     from figaroh_plus_amd import _lib
