@@ -346,6 +346,14 @@ def main():
         sec = kern[k1_name]["avg_ms"] * 1e-3 * launches_per_step[k1_name]  # (the streamed pass runs K1' twice per chunk)
         roof[k1_name] = {"bound": "hbm", "achieved": bytes_per_sample * N / sec / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_sample": bytes_per_sample}
+        if getattr(pipe, "_compact", None) is not None:
+            # block-compact W: the kernel is asked to write the N x 16 |subtree_j| window of every row block, not the
+            # reference's dense rows -- `achieved` / `frac` count the bytes this layout stores (every one of them is written
+            # in every pass); the rate on the reference's dense bytes is kept beside them and is not a fraction of anything
+            stored = 8 * (m.nq + 2 * m.nv) + 8 * float(pipe._compact[1].sum())
+            roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
+                                  "dense_bytes_per_sample": bytes_per_sample,
+                                  "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
     if "fused_chain_tsqr" in kern:
         # one launch does stage A (the regressor, written to HBM) and stage B level 0 (the TSQR of the kept columns, out of
         # LDS): its time is bounded from below by max(algorithmic bytes / HBM peak, algorithmic flops / fp64 peak); the
