@@ -35,8 +35,8 @@ static hipEvent_t acquire_event() {
     return e;
 }
 
-static void *g_ws[32] = {nullptr};
-static size_t g_ws_bytes[32] = {0};
+static void *g_ws[40] = {nullptr};
+static size_t g_ws_bytes[40] = {0};
 
 void set_error(const std::string &msg) { g_error = msg; }
 

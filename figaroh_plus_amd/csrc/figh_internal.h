@@ -118,9 +118,25 @@ struct Tsqr2Job {
     int nlevels;
     int pad_;
 };
+// figh_tsqr_wide_pair.hip: one pair-merge level of SEVERAL stacks (the wide row blocks of a tree's regressor) in one launch
+struct WyPairJob {
+    const double *stack;  // `count` compact nc x nc triangles
+    double *Rblk;         // packed blocks of the job's workgroups
+    double *Rout;         // (count + 1) / 2 triangles
+    long count;
+    int nc;
+    int wg0;              // the job's workgroups are [wg0, wg0 + (count + 1) / 2) of the launch
+};
 }  // namespace figh
 #include <vector>
 namespace figh {
+struct WyPairStack {  // one stack to reduce to one triangle
+    const double *tri;
+    long count;
+    int nc;
+    double *out;
+};
+int reduce_wide_stacks(std::vector<WyPairStack> &stacks);
 int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus);
 // figh_linalg.hip: stack of `count` compact nc x nc triangles -> one; tol_qr >= 0: + rank decision and regrouped rows
 // ((nc + 1) x nc doubles, layout in figh.h, figh_tsqr_selected), else the plain triangle

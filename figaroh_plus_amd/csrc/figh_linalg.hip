@@ -1000,9 +1000,29 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
                                 : static_cast<double *>(workspace(sizeof(double) * (size_t)(rows_total + nc + 1) * nc, 26));
     const int64_t cap_b = std::max(figh_tsqr_level0_capacity(nmax), figh_tsqr_level0_capacity(std::min(nmax, 80)));
     double *tri_b = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax * cap_b, 23));
-    double *Rb = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax, 24));
+    // one triangle per row block (embedded at the end, in block order: an embedding zero-fills nc rows from its offset)
+    double *Rb_all = static_cast<double *>(workspace(sizeof(double) * (size_t)nmax * nmax * nblocks, 24));
     double *one = static_cast<double *>(workspace(tri, 16));
-    if (!stack || !tri_b || !Rb || !one) return FIGH_ERR_ALLOC;
+    if (!stack || !tri_b || !Rb_all || !one) return FIGH_ERR_ALLOC;
+    // the WIDE blocks (more than 80 columns: the blocked kernel, one triangle per workgroup) keep their level-0 triangles
+    // until all of them are there and are then reduced together, level by level (reduce_wide_stacks: one launch per level for
+    // all of them once a level fits the chip -- the levels are latency-bound, 65 us each whatever the number of pairs)
+    size_t wide_doubles = 0;
+    for (int j = 0; j < nblocks; ++j) {
+        const int ncj = h_counts[j] + (d_tau ? 1 : 0);
+        if (h_counts[j] > 0 && ncj > 80) wide_doubles += (size_t)ncj * ncj * (size_t)figh_tsqr_level0_capacity(ncj);
+    }
+    double *wide_tri = wide_doubles ? static_cast<double *>(workspace(sizeof(double) * wide_doubles, 36)) : nullptr;
+    if (wide_doubles && !wide_tri) return FIGH_ERR_ALLOC;
+    size_t wide_at = 0;
+    std::vector<WyPairStack> wide;
+    struct Embed {
+        const double *R;
+        int ncj, nj;
+        const int *pos;
+        double *out;
+    };
+    std::vector<Embed> embeds;
     // The narrow blocks (at most 64 columns with tau: the register-tile kernel's range) of a problem that has several of
     // them go through GROUPED launches (figh_tsqr_group.hip: one level-0 launch, two merge launches, one embedding launch
     // for all of them) after the others -- their embedding writes exactly their own rows of the stack, the per-block
@@ -1036,6 +1056,19 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
             continue;
         }
         int64_t cnt = 0;
+        double *Rb = Rb_all + (size_t)j * nmax * nmax;
+        if (nj > 0 && ncj > 80) {
+            const int64_t cap_j = figh_tsqr_level0_capacity(ncj);
+            double *tri_j = wide_tri + wide_at;
+            wide_at += (size_t)ncj * ncj * (size_t)cap_j;
+            if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_j, cap_j, &cnt, nullptr))
+                return rc;
+            wide.push_back({tri_j, (long)cnt, ncj, Rb});
+            embeds.push_back({Rb, ncj, nj, d_pos + off, stack + (size_t)row_off * nc});
+            row_off += ncj;
+            off += nj;
+            continue;
+        }
         if (nj > 0) {
             if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr))
                 return rc;
@@ -1048,10 +1081,13 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         else if (int rc = tsqr_reduce(tri_b, cnt, ncj, Rb)) return rc;
         // (the embedding zero-fills nc rows from its offset and writes the block's ncj rows: the rows behind them belong to
         // the next block, whose own embedding follows in stream order; the buffer ends nc rows behind the last block)
-        if (int rc = embed_force_triangle(Rb, ncj, nj, d_pos + off, nc, n, stack + (size_t)row_off * nc)) return rc;
+        embeds.push_back({Rb, ncj, nj, d_pos + off, stack + (size_t)row_off * nc});
         row_off += ncj;
         off += nj;
     }
+    if (int rc = reduce_wide_stacks(wide)) return rc;
+    for (const Embed &e : embeds)
+        if (int rc = embed_force_triangle(e.R, e.ncj, e.nj, e.pos, nc, n, e.out)) return rc;
     if (!jobs.empty())
         if (int rc = launch_tsqr_group(jobs, nc, n, cu_count())) return rc;
     if (row_off == 0) {

@@ -97,6 +97,11 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
     // (y (1 + e/2 + 3e^2/8), e = 1 - q y^2: error e^3; r (1 + e + e^2), e = 1 - d r) instead of two Newton steps:
     // 5 + 3 dependent operations instead of 7 + 4
     const double q2 = fma(alpha, alpha, sigma);
+    // NULL PIVOT (dlarfg's H = I rule with a threshold, figh_tsqr_null_pivot_tol): the column is zero to working accuracy
+    // at and below the diagonal -- a linearly dependent column of the regressor, whose residual is rounding noise in every
+    // tile.  Its norm moves into R_kk (which therefore keeps the running residual norm of the column: the test is on
+    // alpha^2 + sigma, so at most null2 of a column's energy is ever folded), the column leaves the tile, and no reflector
+    // is formed: no trailing updates.  q2 is the same number in every lane.
     double rs = __builtin_amdgcn_rsq(q2);
     {
         const double e = fma(-(q2 * rs), rs, 1.0);
@@ -110,23 +115,22 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
     }
     const double inv = copysign(ri, alpha);
     const double tfac = dsum * rs;
-    // NULL PIVOT (dlarfg's H = I rule with a threshold, figh_tsqr_null_pivot_tol): the column is zero to working accuracy
-    // at and below the diagonal -- a linearly dependent column of the regressor, whose residual is rounding noise in every
-    // tile.  Its norm moves into R_kk (which therefore keeps the running residual norm of the column: the test is on
-    // alpha^2 + sigma, so at most null2 of a column's energy is ever folded), the column leaves the tile, and no reflector
-    // is formed: no trailing dot products, no trailing updates.  q2 is the same number in every lane.
     const bool live = __builtin_amdgcn_ballot_w64(q2 > S.null2) != 0;
-    if (live) {
+    // The trailing dot products stay OUTSIDE the test, where the scheduler interleaves them with the rsq / rcp chain as before
+    // (inside it they cost the live steps 5 % and the null steps gain nothing net: same-box A/B, tools/null_ab.py); a null
+    // pivot saves the trailing updates.  Every other arrangement tried -- the test in front of the chain, an else branch of
+    // its own -- made the register allocator spill hundreds of registers.
 #pragma unroll
-        for (int cc = 1; cc < LIVE; ++cc) {
-            double s0 = 0.0, s1 = 0.0;
+    for (int cc = 1; cc < LIVE; ++cc) {
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < NR; i += 2) {
-                fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
-                fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
-            }
-            d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
+        for (int i = 0; i < NR; i += 2) {
+            fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
+            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
         }
+        d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
+    }
+    if (live) {
         // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
         //   - the pivot lane itself gets w = (alpha + sigma inv) tfac = alpha - beta, hence R_kk = alpha - w = beta and
         //     c = w inv = 1: its tile entries x - 1 x vanish (the finished column leaves the tile);

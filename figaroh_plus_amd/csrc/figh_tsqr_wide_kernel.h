@@ -343,15 +343,33 @@ __device__ __forceinline__ void wy_update_lds_chunk(double *__restrict__ lch, co
 // owner until it becomes the last panel.  For column counts one chunk past a register geometry (TALOS: 21 chunks = 4 x 5
 // + 1) this buys the taller tile of the smaller geometry (64 rows with five slots per wave instead of 48 with six).
 template <int NW, int CPW, int NRC, int WPE, bool LDSC, int MODE>
-__global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__restrict__ W_, const long rows_,
-                                                               const long ldw, const int *__restrict__ col_idx,
-                                                               const int n, const double *__restrict__ tau,
+__global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__restrict__ Wp_, const long rowsp_,
+                                                               const long ldwp_, const int *__restrict__ col_idx,
+                                                               const int np_, const double *__restrict__ tau,
                                                                const double *__restrict__ blkw, const long rows_per_blk,
-                                                               double *__restrict__ Rblk, double *__restrict__ Rout,
-                                                               const int nc, long long *__restrict__ prof,
-                                                               const long pair_count, const int aux, const double null2_) {
+                                                               double *__restrict__ Rblkp_, double *__restrict__ Routp_,
+                                                               const int ncp_, long long *__restrict__ prof,
+                                                               const long pair_countp_, const int aux, const double null2_) {
     // MODE 0: level 0 (rows of one tall matrix, tiles dealt round-robin).  MODE 1 = PAIR, MODE 2 = BATCH, below.
-    constexpr bool PAIR = MODE == 1, BATCH = MODE == 2;
+    // MODE 4 = PAIR for several stacks at once (the wide row blocks of a tree's regressor, figh_tsqr_wide_pair.hip): Wp_ is
+    // a device table of `aux` WyPairJob records; the workgroup looks up its job and is then a PAIR workgroup of that job.
+    constexpr bool PAIRG = MODE == 4;
+    constexpr bool PAIR = MODE == 1 || PAIRG, BATCH = MODE == 2;
+    const WyPairJob *job_ = nullptr;
+    if constexpr (PAIRG) {
+        const WyPairJob *jt = reinterpret_cast<const WyPairJob *>(Wp_);
+        int j = 0;
+        for (int k = 1; k < aux; ++k) j = (int)blockIdx.x >= jt[k].wg0 ? k : j;
+        job_ = jt + j;
+    }
+    const unsigned bx = PAIRG ? blockIdx.x - (unsigned)job_->wg0 : blockIdx.x;
+    const double *__restrict__ W_ = PAIRG ? job_->stack : Wp_;
+    const int nc = PAIRG ? job_->nc : ncp_;
+    const long rows_ = PAIRG ? (long)nc : rowsp_, ldw = PAIRG ? (long)nc : ldwp_;
+    const int n = PAIRG ? nc : np_;
+    double *__restrict__ Rblk = PAIRG ? job_->Rblk : Rblkp_;
+    double *__restrict__ Rout = PAIRG ? job_->Rout : Routp_;
+    const long pair_count = PAIRG ? job_->count : pair_countp_;
     // PAIR (pair-merge mode).  W_ is a stack of pair_count compact nc x nc triangles (ldw == nc); workgroup b
     // starts from triangle 2b (copied into its packed blocks: absorbing a triangle into an EMPTY one would cost a full
     // factorisation to reproduce it) and absorbs triangle 2b + 1, tile by tile, all tiles its own (tile i of a triangle
@@ -363,16 +381,16 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     // samples; no row-block weights in this mode).  pair_count = workgroups per matrix: workgroup (b, l) factors the
     // tiles l, l + pair_count, ... of matrix b -- tile t = segment t / tps, rows [M (t % tps), ...) of it, the ragged end
     // of every segment zero-filled by the range check of its own buffer descriptor -- into its own triangle.
-    const long bidx = BATCH ? (long)blockIdx.x / pair_count : 0L;
-    const double *__restrict__ W = PAIR ? W_ + (2L * blockIdx.x + 1) * nc * nc : (BATCH ? W_ + bidx * rows_ * ldw : W_);
+    const long bidx = BATCH ? (long)bx / pair_count : 0L;
+    const double *__restrict__ W = PAIR ? W_ + (2L * bx + 1) * nc * nc : (BATCH ? W_ + bidx * rows_ * ldw : W_);
     // (MODE 3 = CHAIN, chained level-0 launches: the workgroup's own triangle of the previous launch, read back from Rout;
     // a mode of its own for the same reason as PAIR: as a run-time flag of MODE 0 it cost the TALOS geometry 20 more
     // bytes of scratch)
     constexpr bool CHAIN = MODE == 3;
-    const double *__restrict__ Rinit = PAIR ? W_ + (2L * blockIdx.x) * nc * nc
-                                            : (CHAIN ? Rout + (long)blockIdx.x * nc * nc : nullptr);
-    const long rows = PAIR ? ((2L * blockIdx.x + 1 < pair_count) ? (long)nc : 0L) : rows_;
-    const long tile0 = PAIR ? 0L : (BATCH ? (long)blockIdx.x - bidx * pair_count : (long)blockIdx.x);
+    const double *__restrict__ Rinit = PAIR ? W_ + (2L * bx) * nc * nc
+                                            : (CHAIN ? Rout + (long)bx * nc * nc : nullptr);
+    const long rows = PAIR ? ((2L * bx + 1 < pair_count) ? (long)nc : 0L) : rows_;
+    const long tile0 = PAIR ? 0L : (BATCH ? (long)bx - bidx * pair_count : (long)bx);
     const long tstep = PAIR ? 1L : (BATCH ? pair_count : (long)gridDim.x);
     static_assert((NW & (NW - 1)) == 0 && NW >= 2, "NW must be a power of two >= 2");
     static_assert(CPW >= 2, "at least two chunk slots per wave");
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     // kernel would cost if the R blocks came from L2 instead of HBM / MALL
     double *Rb = Rblk + (long)(g_wy_ralias ? (blockIdx.x & 7) : blockIdx.x) * ((long)nch * (nch + 1) / 2) * 256;
 #else
-    double *Rb = Rblk + (long)blockIdx.x * ((long)nch * (nch + 1) / 2) * 256;
+    double *Rb = Rblk + (long)bx * ((long)nch * (nch + 1) / 2) * 256;
 #endif
     auto block = [&](const int p, const int cc) { return Rb + ((long)cc * (cc + 1) / 2 + p) * 256; };
     double *Rl = rpp[wave];
@@ -795,7 +813,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     FIGH_PROF_STORE(prof, wave, NW);
 
     // ---- write this wave's columns of the nc x nc row-major triangle (zeros below the diagonal)
-    double *Ro = Rout + (long)blockIdx.x * nc * nc;
+    double *Ro = Rout + (long)bx * nc * nc;
 #pragma unroll
     for (int s = 0; s < CPW + (LDSC ? 1 : 0); ++s) {
         const int cc = s < CPW ? wave + NW * s : LC;  // (the extra round: the LDS chunk's columns, by its owner)

@@ -2,6 +2,8 @@
 // halves a stack of compact nc x nc triangles: workgroup b starts FROM triangle 2b and absorbs triangle 2b + 1 (tiles of
 // a triangle start at their first non-zero chunk).  The reference has no analogue: this is the reduction of
 // np.linalg.qr(W_e) (src/figaroh/tools/qrdecomposition.py:205) over row blocks.
+#include <cstring>
+
 #include "figh_tsqr_wide_kernel.h"
 
 namespace figh {
@@ -65,6 +67,122 @@ int launch_tsqr_wide_pairs(const double *stack, long count, int nc, double *Rws_
         return FIGH_ERR_UNSUPPORTED;
     }
     FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+// Several stacks (the wide row blocks of a tree's joint-torque regressor: TIAGo has three of 81 .. 96 columns, 768 triangles
+// each) reduced to one triangle each, level by level in lockstep: a level whose pairs of every stack fit the chip at once is
+// latency-bound -- 65 us whatever the number of pairs -- and runs as ONE launch over all the stacks (MODE 4: the workgroup
+// looks up its stack in a device table); a level with more pairs than CUs in some stack runs per stack as before.  The tables
+// of all levels are built up front and uploaded when their content changed (the pipeline repeats the same structure).
+int reduce_wide_stacks(std::vector<WyPairStack> &st) {
+    const int nj = (int)st.size();
+    if (nj == 0) return FIGH_OK;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // buffers: two ping-pong areas and the packed blocks per stack
+    std::vector<size_t> pp_off(nj), blk_off(nj);
+    size_t pp_total = 0, blk_total = 0;
+    for (int j = 0; j < nj; ++j) {
+        const size_t tri = (size_t)st[j].nc * st[j].nc;
+        const int nch = (st[j].nc + 15) >> 4;
+        pp_off[j] = pp_total;
+        pp_total += tri * (size_t)((st[j].count + 1) / 2);
+        blk_off[j] = blk_total;
+        blk_total += (size_t)256 * ((size_t)nch * (nch + 1) / 2) * (size_t)((st[j].count + 1) / 2);
+    }
+    double *pp[2] = {static_cast<double *>(workspace(sizeof(double) * pp_total, 32)),
+                     static_cast<double *>(workspace(sizeof(double) * pp_total, 33))};
+    double *blk = static_cast<double *>(workspace(sizeof(double) * blk_total, 34));
+    if (!pp[0] || !pp[1] || !blk) return FIGH_ERR_ALLOC;
+    struct Level {
+        std::vector<int> grouped;  // stacks of this level's grouped launch
+        std::vector<int> single;   // stacks that take their own launch
+        size_t table_at = 0;       // first record of the grouped launch in the table
+        int nwg = 0;
+    };
+    std::vector<Level> levels;
+    std::vector<WyPairJob> table;
+    std::vector<long> cnt(nj);
+    std::vector<const double *> cur(nj);
+    for (int j = 0; j < nj; ++j) {
+        cnt[j] = st[j].count;
+        cur[j] = st[j].tri;
+        if (cnt[j] == 1)
+            FIGH_HIP(hipMemcpyAsync(st[j].out, st[j].tri, sizeof(double) * (size_t)st[j].nc * st[j].nc, hipMemcpyDeviceToDevice,
+                                    stream()));
+    }
+    struct Single {
+        const double *src;
+        long count;
+        int nc;
+        double *dst;
+    };
+    std::vector<std::vector<Single>> singles;
+    for (int lvl = 0;; ++lvl) {
+        Level L;
+        std::vector<Single> sg;
+        bool any = false;
+        for (int j = 0; j < nj; ++j) {
+            if (cnt[j] <= 1) continue;
+            any = true;
+            const long nb = (cnt[j] + 1) / 2;
+            double *dst = nb == 1 ? st[j].out : pp[lvl & 1] + pp_off[j];
+            const int nch = (st[j].nc + 15) >> 4;
+            if (nb > cus || nch > 16) {
+                sg.push_back({cur[j], cnt[j], st[j].nc, dst});
+                L.single.push_back(j);
+            } else {
+                WyPairJob J;
+                J.stack = cur[j];
+                J.Rblk = blk + blk_off[j];
+                J.Rout = dst;
+                J.count = cnt[j];
+                J.nc = st[j].nc;
+                J.wg0 = L.nwg;
+                if (L.grouped.empty()) L.table_at = table.size();
+                table.push_back(J);
+                L.grouped.push_back(j);
+                L.nwg += (int)nb;
+            }
+            cur[j] = dst;
+            cnt[j] = nb;
+        }
+        if (!any) break;
+        levels.push_back(L);
+        singles.push_back(sg);
+    }
+    const size_t tb = sizeof(WyPairJob) * table.size();
+    const WyPairJob *d_table = nullptr;
+    if (tb) {
+        char *devp = static_cast<char *>(workspace(tb, 35));
+        if (!devp) return FIGH_ERR_ALLOC;
+        static std::vector<char> cached;
+        static const char *cached_dev = nullptr;
+        std::vector<char> blob(tb);
+        std::memcpy(blob.data(), table.data(), tb);
+        if (cached_dev != devp || cached != blob) {
+            FIGH_HIP(hipMemcpyAsync(devp, blob.data(), tb, hipMemcpyHostToDevice, stream()));
+            FIGH_HIP(hipStreamSynchronize(stream()));  // (blob is host memory of this call)
+            cached = blob;
+            cached_dev = devp;
+        }
+        d_table = reinterpret_cast<const WyPairJob *>(devp);
+    }
+    for (size_t l = 0; l < levels.size(); ++l) {
+        ProfileScope scope("tsqr_reduce");
+        for (const Single &s : singles[l])
+            if (int rc = launch_tsqr_wide_pairs(s.src, s.count, s.nc, s.dst)) return rc;
+        const Level &L = levels[l];
+        if (!L.grouped.empty()) {
+            hipLaunchKernelGGL((tsqr_wy_kernel<8, 2, 8, 2, false, 4>), dim3((unsigned)L.nwg), dim3(512), 0, stream(),
+                               reinterpret_cast<const double *>(d_table + L.table_at), 0L, 0L, (const int *)nullptr, 0,
+                               (const double *)nullptr, (const double *)nullptr, 1L, (double *)nullptr, (double *)nullptr, 0,
+                               (long long *)nullptr, 0L, (int)L.grouped.size(), null_pivot_sq());
+            FIGH_HIP(hipGetLastError());
+        }
+    }
     return FIGH_OK;
 }
 
