@@ -433,17 +433,17 @@ def main():
                     roof[key]["traffic_source"] = ("profiles/%s: a committed rocprofv3 --pmc run of this command, NOT "
                                                    "measured in this run" % pmc_file)
         if args.config == "cfg4" and N == 4_000_000:
-            pmc4 = next(n for n in ("r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
+            pmc4 = next(n for n in ("r04_pmc_summary_cfg4.json", "r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
                         if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", pmc4)) as f:
                 pmc = json.load(f)
             src = "profiles/%s: a committed rocprofv3 --pmc run of this command, NOT measured in this run" % pmc4
-            for key, kname in (("regressor_tree", "regressor_tape_kernel<16, true, true, true, true>"),
-                               ("tsqr", "tsqr_wy_kernel<4, 5, 4, 2, true>")):
+            wy = next((n for n in ("tsqr_wy_kernel<4, 5, 4, 2, true, 0>", "tsqr_wy_kernel<4, 5, 4, 2, true>") if n in pmc), "")
+            for key, kname in (("regressor_tree", "regressor_tape_kernel<16, true, true, true, true>"), ("tsqr", wy)):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
-                    roof[key]["traffic_source"] = src
-            k = pmc.get("tsqr_wy_kernel<4, 5, 4, 2, true>", {})
+                    roof[key]["traffic_source"] = src + (" (the torque-row launch of the two level-0 launches)" if key == "tsqr" else "")
+            k = pmc.get(wy, {})
             if "tsqr" in roof and "SQ_INSTS_VALU_MFMA_MOPS_F64" in k:
                 # one MOPS unit = 512 flops (4 units per v_mfma_f64_16x16x4 = 2048 flops, checked against SQ_INSTS_MFMA)
                 roof["tsqr"]["executed_mfma_flops_per_launch"] = 512.0 * k["SQ_INSTS_VALU_MFMA_MOPS_F64"]
