@@ -152,7 +152,7 @@ CONFIGS = {  # BASELINE.json configs[1..4]: (golden fixture, model, samples in t
     "cfg2": ("cfg2_ur10", "ur10", 1_000_000, None),
     "cfg3": ("cfg3_tiago", "tiago", 1_000_000, None),
     "cfg4": ("cfg4_talos", "talos", 4_000_000, None),
-    "cfg5": ("cfg5_human", "human", 10_000_000, 500_000),
+    "cfg5": ("cfg5_human", "human", 10_000_000, 2_500_000),  # (67 GB of W per chunk; 500 000: +12 % step time, tools/chunk_sweep.sh)
 }
 
 
@@ -167,6 +167,8 @@ def main():
                     help="weak: --samples per GPU (default for cfg2); strong: the config's total sharded over the GPUs "
                          "(default for cfg3-5)")
     ap.add_argument("--samples", type=int, default=None, help="samples per GPU (weak) / in total (strong)")
+    ap.add_argument("--chunk-samples", type=int, default=None,
+                    help="cfg5: samples per chunk of the streamed pass (default: the config's 2 500 000)")
     ap.add_argument("--cpu-samples", type=int, default=None,
                     help="samples of the CPU baseline legs (default: 300000 for cfg2, 20000 for cfg3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,6 +237,8 @@ def main():
             group.barrier()
 
     fixture, model_name, n_config, chunk = CONFIGS[args.config]
+    if args.chunk_samples and chunk:
+        chunk = args.chunk_samples
     scaling = args.scaling or ("weak" if args.config == "cfg2" else "strong")
     with open(os.path.join(ROOT, "tests", "golden", fixture + ".json")) as f:
         meta = json.load(f)
