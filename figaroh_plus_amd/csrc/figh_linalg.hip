@@ -31,12 +31,12 @@
 namespace figh {
 
 
-template <int NCC, int NRC, bool LDSRED>
-__global__ __launch_bounds__(64, NCC <= 4 ? 2 : 1) void tsqr2_kernel(
+template <int NCC, int NRC, bool LDSRED, bool RLAST = false>
+__global__ __launch_bounds__(64, (NCC <= 4 || RLAST) ? 2 : 1) void tsqr2_kernel(
     const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
     const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
     double *__restrict__ Rws, const int nc, const int *__restrict__ tile_first, const double null2) {
-    tsqr2_level0_body<NCC, NRC, LDSRED>(W, rows, ldw, col_idx, n, tau, blkw, rows_per_blk, Rws, nc, tile_first,
+    tsqr2_level0_body<NCC, NRC, LDSRED, RLAST>(W, rows, ldw, col_idx, n, tau, blkw, rows_per_blk, Rws, nc, tile_first,
                                         (long)blockIdx.x, (long)gridDim.x, null2);
 }
 
@@ -407,11 +407,11 @@ static int cu_count() {
 
 
 // LDS of one tsqr2 wave: 64 doubles of reduction scratch + the packed triangle minus the rows of the padding columns
-static size_t tsqr2_lds_bytes(int ncc, int nc) {
-    const int pad = 16 * ncc - nc;
+static size_t tsqr2_lds_bytes(int ncc, int nc, bool rlast = false) {
+    const int pad = 16 * ncc - nc, lch = rlast ? ncc - 1 : ncc;
     size_t skip = 0;
-    for (int kp = 0; kp < pad; ++kp) skip += 16 * (ncc - (kp >> 4));
-    return sizeof(double) * (64 + 256 * (size_t)(ncc * ncc - (ncc * (ncc - 1)) / 2) - skip);
+    for (int kp = 0; kp < pad; ++kp) skip += 16 * (lch - (kp >> 4) > 0 ? lch - (kp >> 4) : 0);
+    return sizeof(double) * ((rlast ? 80 : 64) + 256 * (size_t)(lch * lch - (lch * (lch - 1)) / 2) - skip);
 }
 
 // per-tile structure hint of the register-tile kernel: g_tile_hint is installed by figh_tsqr_hint_begin for the level-0
@@ -469,12 +469,24 @@ static int tsqr_level(const double *W, long rows, long ldw, const int *col_idx, 
     const int *th = hint ? hint : zero_tile_hint(ntiles);
     if (!th) return FIGH_ERR_ALLOC;
     dim3 grid((unsigned)nw), block(64);
+    bool tall48 = nc > 64 && !hint && rows >= 6L * nc * cu_count() * 8;
+#ifdef FIGH_ABLATION
+    if (const char *e = getenv("FIGH_T53")) tall48 = nc > 64 && !hint && atoi(e) != 0;
+#endif
     if (nc <= 64)
         FIGH_LAUNCH_TIMED((tsqr2_kernel<4, 4, true>), grid, block, tsqr2_lds_bytes(4, nc), W, rows, ldw, col_idx, n, tau,
                           d_blkw, rows_per_blk, Rws_out, nc, th, null_pivot_sq());
-    else
+    else if (!tall48)
         FIGH_LAUNCH_TIMED((tsqr2_kernel<5, 4, false>), grid, block, tsqr2_lds_bytes(5, nc), W, rows, ldw, col_idx, n, tau,
                           d_blkw, rows_per_blk, Rws_out, nc, th, null_pivot_sq());
+    else {
+        // 65 .. 80 columns without a structure hint: 48-row tiles and the last triangle chunk in registers -- 17 KB of LDS and
+        // < 256 registers per wave, two waves per SIMD (the 64-row form is alone on its SIMD: latency-bound)
+        const int *th3 = zero_tile_hint((rows + 47) / 48);
+        if (!th3) return FIGH_ERR_ALLOC;
+        FIGH_LAUNCH_TIMED((tsqr2_kernel<5, 3, false, true>), grid, block, tsqr2_lds_bytes(5, nc, true), W, rows, ldw, col_idx, n,
+                          tau, d_blkw, rows_per_blk, Rws_out, nc, th3, null_pivot_sq());
+    }
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }
@@ -693,8 +705,15 @@ int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t
     // SIMD, and as many waves per CU as the LDS triangles admit; wide kernel: occupancy of its workgroups)
     long target;
     if (nc <= 80) {
-        long per_cu = (long)((160 * 1024) / tsqr2_lds_bytes(nc <= 64 ? 4 : 5, nc));
-        if (per_cu > (nc <= 64 ? 8 : 4)) per_cu = nc <= 64 ? 8 : 4;
+        // (65 .. 80 columns without a structure hint: the 48-row form with its register chunk, two waves per SIMD)
+        // -- when there are rows for eight waves per CU (same-box A/B in alternating order, tools/t53_ab.py: 3e6 x 77: 2.10-2.21
+        // against 2.30-2.45 ms, 1e6 x 66: 0.74 against 0.85-0.92 ms, 1e6 x 80: equal; 5e5 x 80: 0.59-0.61 against 0.53-0.75)
+        bool small_lds = nc > 64 && !g_tile_hint && rows >= 6L * nc * cu_count() * 8;
+#ifdef FIGH_ABLATION
+        if (const char *e = getenv("FIGH_T53")) small_lds = nc > 64 && !g_tile_hint && atoi(e) != 0;  // 1: always, 0: never
+#endif
+        long per_cu = (long)((160 * 1024) / tsqr2_lds_bytes(nc <= 64 ? 4 : 5, nc, small_lds));
+        if (per_cu > ((nc <= 64 || small_lds) ? 8 : 4)) per_cu = (nc <= 64 || small_lds) ? 8 : 4;
         if (per_cu < 1) per_cu = 1;
         target = cu_count() * per_cu;
     } else {

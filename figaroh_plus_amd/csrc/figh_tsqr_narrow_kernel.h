@@ -9,7 +9,7 @@
 
 namespace figh {
 
-template <int NCC, int NRC, bool LDSRED>
+template <int NCC, int NRC, bool LDSRED, bool RLAST = false>
 __device__ __forceinline__ void tsqr2_level0_body(
     const double *__restrict__ W, const long rows, const long ldw, const int *__restrict__ col_idx, const int n,
     const double *__restrict__ tau, const double *__restrict__ blkw, const long rows_per_blk,
@@ -34,11 +34,21 @@ __device__ __forceinline__ void tsqr2_level0_body(
     // nc = 50 the chunk holding 2 real columns is then live for 2 steps instead of 50 (-33 % chunk-steps on UR10).
     const int pad = 16 * NCC - nc;
     // LDS: [64 doubles of reduction scratch][packed triangle without the rows of the padding columns]
+    // RLAST (figh_tsqr_narrow.h): the last 16 lane-columns of the triangle live in registers, 16 doubles of LDS pass a row of
+    // them between the row groups, and the packed triangle has LCH = NCC - 1 chunks per row -- for 65 .. 80 columns 17 instead
+    // of 28 KB per wave, i.e. two waves per SIMD instead of five per CU
+    constexpr int LCH = RLAST ? NCC - 1 : NCC;
+    constexpr int HEAD = RLAST ? 80 : 64;
     int skip = 0;
-    for (int kp = 0; kp < pad; ++kp) skip += 16 * (NCC - (kp >> 4));
-    Tsqr2State<NCC, NRC> S;
+    for (int kp = 0; kp < pad; ++kp) skip += 16 * (LCH - (kp >> 4) > 0 ? LCH - (kp >> 4) : 0);
+    Tsqr2State<NCC, NRC, RLAST> S;
     S.red = Rl;
-    S.Rl = Rl + 64 - skip;
+    S.bc = Rl + 64;
+    S.Rl = Rl + HEAD - skip;
+    if constexpr (RLAST) {
+#pragma unroll
+        for (int sl = 0; sl < 4 * NCC; ++sl) S.Rq[sl] = 0.0;
+    }
     S.lane_c = lane & 15;
     S.lane_g = lane >> 4;
     S.nc = nc;
@@ -61,8 +71,8 @@ __device__ __forceinline__ void tsqr2_level0_body(
 #pragma unroll
         for (int i = 0; i < RPL; ++i) S.T[cc][i] = 0.0;
     {
-        constexpr int tot = 256 * (NCC * NCC - (NCC * (NCC - 1)) / 2);
-        for (int e = lane; e < 64 + tot - skip; e += 64) Rl[e] = 0.0;
+        constexpr int tot = 256 * (LCH * LCH - (LCH * (LCH - 1)) / 2);
+        for (int e = lane; e < HEAD + tot - skip; e += 64) Rl[e] = 0.0;
     }
     __syncthreads();
 
@@ -189,7 +199,7 @@ __device__ __forceinline__ void tsqr2_level0_body(
         // but a null pivot would keep it as its |R_kk| (tools/null_pivot_noise.py)
         S.null2 = absorbed * M < nc + M / 8 ? 0.0 : null2;
         ++absorbed;
-        tsqr2_panels<0, NCC, NRC, LDSRED>(S, first_nz, [&](auto P) {
+        tsqr2_panels<0, NCC, NRC, LDSRED, RLAST>(S, first_nz, [&](auto P) {
             if constexpr (decltype(P)::value < NCC - 1) {
                 if (next_fast) load_chunk(P, r0n, fposn);
             }
@@ -198,13 +208,23 @@ __device__ __forceinline__ void tsqr2_level0_body(
     }
     __syncthreads();
     double *Rg = Rws + wave * (long)nc * nc;
+    const int nlds = 16 * LCH - pad;  // columns of the compact triangle that live in LDS
     for (int e = lane; e < nc * nc; e += 64) {
         const int k = e / nc, col = e - k * nc;
+        if (RLAST && col >= nlds && col >= k) continue;  // (written from the registers below)
         const int kp = k + pad, colp = col + pad;  // padded positions
         const int pk = kp >> 4;
         Rg[e] = (k >= nc || col < k)  // below the diagonal the LDS rows hold rounding residues, not results
                     ? 0.0
-                    : S.Rl[256 * (pk * NCC - (pk * (pk - 1)) / 2) + (kp & 15) * 16 * (NCC - pk) + (colp - 16 * pk)];
+                    : S.Rl[tsqr2_panel_off<LCH>(pk) + (kp & 15) * 16 * (LCH - pk) + (colp - 16 * pk)];
+    }
+    if constexpr (RLAST) {
+        const int col = 16 * LCH + S.lane_c - pad;
+#pragma unroll
+        for (int sl = 0; sl < 4 * NCC; ++sl) {
+            const int k = 4 * sl + S.lane_g - pad;
+            if (k >= 0 && col >= k && col >= 0 && col < nc) Rg[(long)k * nc + col] = S.Rq[sl];
+        }
     }
 }
 
