@@ -48,6 +48,10 @@
 #include "figh_spatial.h"
 #include "figh_wave.h"
 
+#ifndef FIGH_TREE_LSP
+#define FIGH_TREE_LSP 18  // LDS row stride of the segment tile in doubles (see regressor_tape_kernel)
+#endif
+
 namespace figh {
 
 enum : int32_t { OP_RESET = 0, OP_STEP = 1, OP_EMIT = 2, OP_ZERO = 3, OP_TX40 = 4, OP_FETCH = 5 };
@@ -80,6 +84,7 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
                                            double *__restrict__ W, const long ldw, const unsigned ldw8, const long rowbase,
                                            const int col0, const bool skip_lo = false, const int col0_acc = -1) {
     constexpr int CP = LS / 2, RPI = 64 / CP;  // 16-byte chunks per row, rows per store instruction
+    constexpr int LSP = FIGH_TREE_LSP;         // LDS row stride of the tile (see regressor_tape_kernel)
     const int rg = lane / CP, ch = lane - rg * CP;
     const bool active = rg < RPI;
     double acc0 = 0.0, acc1 = 0.0;
@@ -91,7 +96,7 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
         for (int it = 0; it < (64 + RPI - 1) / RPI; ++it) {
             const int row = RPI * it + rg;
             if (row < nvalid) {
-                const double2 x = *reinterpret_cast<const double2 *>(tile + row * LS + 2 * ch);
+                const double2 x = *reinterpret_cast<const double2 *>(tile + row * LSP + 2 * ch);
                 if constexpr (COLSQ) {
                     acc0 = fma(x.x, x.x, acc0);
                     acc1 = fma(x.y, x.y, acc1);
@@ -167,8 +172,14 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                                                             const long ldw, const int ncols_int,
                                                             double *__restrict__ colsq_part) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *tile = lds;           // 64 x LS
-    double *red = lds + 64 * LS;  // 64 x 2
+    // The tile's rows are LS + 2 doubles apart in LDS: a lane writes ITS row (one sample), and with the rows 128 bytes apart
+    // (LS = 16) all 64 lanes of a ds_write hit the same four banks -- 64 cycles per instruction instead of 8, fourteen doubles
+    // per segment, and the flush's ds_read_b128 (8 rows x 8 chunks per instruction) 8-way on top: the kernel spent its time
+    // in LDS (TALOS: 198 segments per tile, ~1200 LDS cycles each = the whole 24 ms; a store-only tape ran 2.2 x faster).
+    // 144 bytes (both segment widths): rows stay 16-byte aligned, eight consecutive rows cover all 32 banks.
+    constexpr int LSP = FIGH_TREE_LSP;
+    double *tile = lds;            // 64 x LSP
+    double *red = lds + 64 * LSP;  // 64 x 2
     double *colacc = red + 128;   // ncols_int (COLSQ): column sums in the kernel's own (LS-strided) numbering
     const int lane = threadIdx.x;
     const unsigned ldw8 = 8u * (unsigned)ldw;
@@ -180,8 +191,8 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
         for (int e = lane; e < ncols_int; e += 64) colacc[e] = 0.0;
     }
     if constexpr (LS == 16) {  // the two padding columns of the tile are written once
-        tile[16 * lane + 14] = 0.0;
-        tile[16 * lane + 15] = 0.0;
+        tile[LSP * lane + 14] = 0.0;
+        tile[LSP * lane + 15] = 0.0;
     }
     const double g0 = M->gravity[0], g1 = M->gravity[1], g2 = M->gravity[2];
     const long ntiles = (N + 63) / 64;
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
 #pragma unroll
                     for (int d = 0; d < 3; ++d) accv[d] = A[d] + tt[d];
                 }
-                double *my = tile + LS * lane;
+                double *my = tile + LSP * lane;
 #pragma unroll 1
                 for (int c = 0; c < (EXTFF ? 6 : 1); ++c) {
                     double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                     } else {  // odd column count / unaligned W: plain 8-byte stores, no fused norms
                         for (int id = lane; id < nvalid * 14; id += 64) {
                             const int row = id / 14, col = id - 14 * row;
-                            W[(rowbase + row) * ldw + col0 + col] = tile[row * LS + col];
+                            W[(rowbase + row) * ldw + col0 + col] = tile[row * LSP + col];
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -717,8 +728,11 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const size_t lds = sizeof(double) * (64 * (size_t)ls + 128 + (size_t)(fuse ? ncols_int : 0));
+    const size_t lds = sizeof(double) * (64 * (size_t)FIGH_TREE_LSP + 128 + (size_t)(fuse ? ncols_int : 0));
     long grid = (long)cus * 8;
+#ifdef FIGH_ABLATION
+    if (const char *e = getenv("FIGH_TREE_WAVES")) grid = (long)cus * atoi(e);
+#endif
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     double *part = nullptr;
