@@ -882,6 +882,30 @@ def test_tsqr_shapes_against_lapack(lib, n, rows):
         assert np.abs(Ra.T @ Ra - Ga).max() <= 1e-12 * np.abs(Ga).max()
 
 
+@pytest.mark.parametrize("n,rows", [(65, 850013), (72, 1000000), (79, 1000003), (80, 1250000)])
+def test_tsqr_tall_65_to_80_columns_uses_the_48_row_form(lib, n, rows):
+    """65 .. 80 columns and rows for eight waves per CU: level 0 runs as tsqr2_kernel<5, 3, false, true> (48-row tiles, last
+    triangle chunk in registers, figh_linalg.hip) -- R^T R = A^T A, |diag R| equals LAPACK's, with and without tau, ragged
+    last tile, gathered columns out of a wider matrix."""
+    from figaroh_plus_amd.tools.qrdecomposition import rfactor
+    rng = np.random.default_rng(n + rows)
+    ld = n + 9
+    W = rng.standard_normal((rows, ld)) * rng.uniform(0.5, 20.0, ld)
+    cols = np.sort(rng.choice(ld, n - 1, replace=False)).astype(np.int32)
+    t = rng.standard_normal(rows)
+    A = np.c_[W[:, cols], t]
+    G = A.T @ A
+    R = rfactor(W, tau=t, col_idx=cols)
+    assert R.shape == (n, n) and np.array_equal(R, np.triu(R))
+    assert np.abs(R.T @ R - G).max() <= 1e-12 * np.abs(G).max()
+    ref = np.linalg.qr(A[:200000], mode="r")  # (LAPACK on the whole matrix takes minutes: the Gram test above covers all rows)
+    R2 = rfactor(W[:200000], tau=t[:200000], col_idx=cols)  # fewer rows: the 64-row form
+    assert np.abs(np.abs(np.diag(R2)) - np.abs(np.diag(ref))).max() <= 1e-9 * np.abs(np.diag(ref)).max()
+    Rn = rfactor(A[:, :n - 1] if n < 80 else A)  # no tau / all columns
+    Gn = G[:Rn.shape[0], :Rn.shape[0]]
+    assert np.abs(Rn.T @ Rn - Gn).max() <= 1e-12 * np.abs(Gn).max()
+
+
 def _rank_deficient(rng, rows, n, ndep):
     """rows x n, ndep of the columns (at random places, never the first) exact combinations of columns in front of them"""
     A = rng.standard_normal((rows, n)) * rng.uniform(0.5, 20.0, n)
