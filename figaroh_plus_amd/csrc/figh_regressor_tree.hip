@@ -82,12 +82,14 @@ template <int LS, bool STORE, bool COLSQ>
 __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, double *__restrict__ red,
                                            double *__restrict__ colacc, const int lane, const int nvalid,
                                            double *__restrict__ W, const long ldw, const unsigned ldw8, const long rowbase,
-                                           const int col0, const bool skip_lo = false, const int col0_acc = -1) {
+                                           const int col0, double &acc0, double &acc1, const bool fold,
+                                           const bool skip_lo = false, const int col0_acc = -1) {
     constexpr int CP = LS / 2, RPI = 64 / CP;  // 16-byte chunks per row, rows per store instruction
     constexpr int LSP = FIGH_TREE_LSP;         // LDS row stride of the tile (see regressor_tape_kernel)
     const int rg = lane / CP, ch = lane - rg * CP;
     const bool active = rg < RPI;
-    double acc0 = 0.0, acc1 = 0.0;
+    // (acc0, acc1: this lane's column pair, summed over its rows -- and, external-wrench mode, over the six row blocks of the
+    // link, which share their columns: ONE fold per link instead of six)
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(W + rowbase * ldw + col0, (short)0, 0x7fffffff, 0x00020000);
     const unsigned voff = (unsigned)rg * ldw8 + 16u * (unsigned)ch;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
             }
         }
     }
-    if constexpr (COLSQ) {  // fold the row groups in fixed order: bit-reproducible
+    if (COLSQ && fold) {  // fold the row groups in fixed order: bit-reproducible
         red[2 * lane] = active ? acc0 : 0.0;
         red[2 * lane + 1] = active ? acc1 : 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -131,6 +133,7 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        acc0 = acc1 = 0.0;
     }
 }
 
@@ -374,17 +377,19 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                     for (int d = 0; d < 3; ++d) accv[d] = A[d] + tt[d];
                 }
                 double *my = tile + LSP * lane;
+                double cs0 = 0.0, cs1 = 0.0;  // column norms of the segment (flush_tile)
 #pragma unroll 1
                 for (int c = 0; c < (EXTFF ? 6 : 1); ++c) {
+                    const bool fold = !EXTFF || c == 5;
                     double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                     if constexpr (EXTFF) {
                         if ((od >> c) & 1) {  // unit twist c of the root-joint frame, seen from the link
                             double jl[3], ja[3];
-                            if (c < 3) {
+                            if (c < 3) {  // (a force row: Ja = 0, the rotational-inertia entries stay exact zeros)
                                 jl[0] = Rc[3 * c];
                                 jl[1] = Rc[3 * c + 1];
                                 jl[2] = Rc[3 * c + 2];
-                                ja[0] = ja[1] = ja[2] = 0.0;
+                                axis_times_body_regressor_lin(jl, accv, A + 3, V + 3, o);
                             } else {
                                 const int kk = c - 3;
                                 ja[0] = Rc[3 * kk];
@@ -395,8 +400,8 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                                 tt[1] = kk == 0 ? -pc[2] : (kk == 1 ? 0.0 : pc[0]);
                                 tt[2] = kk == 0 ? pc[1] : (kk == 1 ? -pc[0] : 0.0);
                                 rotT(Rc, tt, jl);
+                                axis_times_body_regressor(jl, ja, accv, A + 3, V + 3, o);
                             }
-                            axis_times_body_regressor(jl, ja, accv, A + 3, V + 3, o);
                         }
                     } else {
                         if (oc & EMIT_INERT) axis_times_body_regressor(Jl, Ja, accv, A + 3, V + 3, o);
@@ -416,13 +421,13 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                             // segment's column in it | ld << 16, oe = the prefix sum
                             const long ldc = od >> 16;
                             flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W + (long)N * oe, ldc,
-                                                         8u * (unsigned)ldc, i0, (od & 0xffff) - 1, false, col0);
+                                                         8u * (unsigned)ldc, i0, (od & 0xffff) - 1, cs0, cs1, fold, false, col0);
                         } else {
 #ifdef FIGH_ABLATION
-                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0,
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0, cs0, cs1, fold,
                                                          EXTFF && g_tree_half && c < 3);
 #else
-                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0);
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0, cs0, cs1, fold);
 #endif
                         }
                     } else {  // odd column count / unaligned W: plain 8-byte stores, no fused norms

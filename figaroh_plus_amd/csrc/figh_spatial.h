@@ -68,4 +68,18 @@ __device__ __forceinline__ void axis_times_body_regressor(const double *Jl, cons
     o[5] = dw[2] * Ja[2] - w[2] * u[2];                                              // Izz
 }
 
+// ... for a pure translation axis (Ja = 0: the three force rows of the external-wrench regressor): the six rotational-inertia
+// entries are exact zeros and mx my mz lose their acc x Ja term -- 40 instead of 110 flops.  o[0 .. 5] are not written.
+__device__ __forceinline__ void axis_times_body_regressor_lin(const double *Jl, const double *acc, const double *dw,
+                                                              const double *w, double *o) {
+    o[9] = Jl[0] * acc[0] + Jl[1] * acc[1] + Jl[2] * acc[2];  // m
+    double h1[3], h2[3], h3[3];                                 // mx my mz: Jl x dw + w x (w x Jl)
+    cross3(Jl, dw, h1);
+    cross3(w, Jl, h2);
+    cross3(w, h2, h3);
+    o[6] = h1[0] + h3[0];
+    o[7] = h1[1] + h3[1];
+    o[8] = h1[2] + h3[2];
+}
+
 }  // namespace figh
