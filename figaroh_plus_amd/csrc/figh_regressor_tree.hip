@@ -227,8 +227,8 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
         for (int s = 0; s < kFetch; ++s) sq0[s] = sq1[s] = sqd[s] = sqdd[s] = 0.0;
         double last_qd = 0.0, last_qdd = 0.0;  // of the joint stepped last (Ia / fv / fs of its own row)
         for (int pcnt = 0; pcnt < ntape; ++pcnt) {
-            const int op = tape[pcnt].op, oa = tape[pcnt].a, ob = tape[pcnt].b, oc = tape[pcnt].c, od = tape[pcnt].d,
-                      oe = tape[pcnt].e;
+            int op = tape[pcnt].op, oa = tape[pcnt].a, ob = tape[pcnt].b, oc = tape[pcnt].c, od = tape[pcnt].d,
+                oe = tape[pcnt].e;
             if (op == OP_STEP) {
                 // ---- forward step onto joint k (restates the first loop of pinocchio::computeJointTorqueRegressor)
                 const int k = oa;
@@ -353,7 +353,20 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                         }
                     }
                 }
-            } else if (op == OP_EMIT) {
+                // A STEP that is followed by the EMIT of its link runs it in the SAME iteration: every trip through the loop
+                // latch copies the whole kinematic state (50 doubles: the register allocator does not keep it in place across
+                // the op branches), and half of the ops of a tape are such EMITs
+                if (pcnt + 1 < ntape && tape[pcnt + 1].op == OP_EMIT) {
+                    ++pcnt;
+                    op = OP_EMIT;
+                    oa = tape[pcnt].a;
+                    ob = tape[pcnt].b;
+                    oc = tape[pcnt].c;
+                    od = tape[pcnt].d;
+                    oe = tape[pcnt].e;
+                }
+            }
+            if (op == OP_EMIT) {
                 // ---- the segment of link oa: EXTFF in all six row blocks (od = components with inertial entries),
                 // otherwise in row block ob
                 const int b = oa, col0 = LS * (b - 1);
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                 for (int d = 0; d < 9; ++d) Rc[d] = (d % 4 == 0) ? 1.0 : 0.0;
                 pc[0] = pc[1] = pc[2] = 0.0;
                 jactive = false;
-            } else {  // OP_TX40 (regressor.py:198-227, fused): columns 14 nl .. + 2 on the six joint rows
+            } else if (op == OP_TX40) {  // (regressor.py:198-227, fused): columns 14 nl .. + 2 on the six joint rows
                 if constexpr (STORE) {
                     if (lane < nvalid) {
                         const double sc = sgn(vi[4 * is] + vi[5 * is]);
