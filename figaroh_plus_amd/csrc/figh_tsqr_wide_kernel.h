@@ -106,7 +106,12 @@ struct TColumn<M1, M1> {
 template <int KK, int RPL>
 __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, double *__restrict__ Rl,
                                               double *__restrict__ Tl, double *__restrict__ red, const int lane,
-                                              const int c, const double null2) {
+                                              const int c_, const double null2) {
+    // (the lane's column, opaque per step: the comparisons with KK below are then two v_cmp here -- hoisted out of the sixteen
+    // steps they become 32 lane masks in SGPR pairs that the allocator parks in VGPR lanes and fetches back with four
+    // v_readlane per step)
+    int c = c_;
+    asm volatile("" : "+v"(c));
     double rk = Rl[KK * 16 + c];  // row KK of the diagonal block: requested before the dot products
     constexpr int KH = KK < 8 ? KK : 8;
     double tr[8];
