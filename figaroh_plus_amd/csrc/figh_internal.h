@@ -116,7 +116,7 @@ struct Tsqr2Job {
     int wave0, nwaves;     // level 0: waves [wave0, wave0 + nwaves) of the launch
     int wg0[3], nb[3];     // merge level l: workgroups [wg0[l], wg0[l] + nb[l]) of its launch (nb[l] == 0: level unused)
     int nlevels;
-    int pad_;
+    int tall;              // level 0 in the one-chunk form with 256-row tiles (nc <= 16)
 };
 // figh_tsqr_wide_pair.hip: one pair-merge level of SEVERAL stacks (the wide row blocks of a tree's regressor) in one launch
 struct WyPairJob {

@@ -28,13 +28,21 @@ namespace figh {
 // ------------------------------------------------------------------------------------------------ level 0
 // tsqr2_kernel<4, 4, true>'s body (figh_tsqr_narrow_kernel.h: all loads of a tile in flight, next tile's chunks requested
 // into retired registers, 8-way interleaved tile order) on the job's matrix; `zeros` = a structure hint of all zeros.
+// Two forms of the body in one kernel (wave-uniform choice per job): <4, 4> = up to 64 columns, 64-row tiles; <1, 16> = at
+// most 16 columns (with tau) -- ONE column chunk and 256-row tiles in the same 128 registers: a quarter of the column steps
+// per row (the wheel, caster, head and gripper blocks of TIAGo have 8 .. 15 columns; their tiles are issue-bound on the
+// steps' fixed part).  One launch for both kinds: separately neither fills the chip.
 __global__ __launch_bounds__(64, 2) void tsqr2_group_kernel(const Tsqr2Job *__restrict__ jobs,
                                                             const int *__restrict__ job_of_wave,
                                                             const int *__restrict__ zeros, const double null2) {
     const int jid = __builtin_amdgcn_readfirstlane(job_of_wave[blockIdx.x]);
     const Tsqr2Job *J = jobs + jid;
-    tsqr2_level0_body<4, 4, true>(J->W, J->rows, J->ldw, J->col_idx, J->n, J->tau, (const double *)nullptr, 1L, J->tri, J->nc,
-                                  zeros, (long)blockIdx.x - J->wave0, (long)J->nwaves, null2);
+    if (J->tall)  // (tall form, chosen by the host)
+        tsqr2_level0_body<1, 16, true>(J->W, J->rows, J->ldw, J->col_idx, J->n, J->tau, (const double *)nullptr, 1L, J->tri,
+                                       J->nc, zeros, (long)blockIdx.x - J->wave0, (long)J->nwaves, null2);
+    else
+        tsqr2_level0_body<4, 4, true>(J->W, J->rows, J->ldw, J->col_idx, J->n, J->tau, (const double *)nullptr, 1L, J->tri,
+                                      J->nc, zeros, (long)blockIdx.x - J->wave0, (long)J->nwaves, null2);
 }
 
 // ------------------------------------------------------------------------------------------------ merge levels
@@ -105,10 +113,12 @@ int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cu
     int max_nc = 1;
     for (int j = 0; j < njobs; ++j) {
         Tsqr2Job &J = jobs[j];
-        const long ntiles = (J.rows + 63) / 64;
+        const bool tall = J.nc <= 16 && J.rows >= 256L * 64;
+        const long ntiles = tall ? (J.rows + 255) / 256 : (J.rows + 63) / 64;
         long nw = std::min(std::min(ntiles / 8, 512L), per_job_cap);
         if (nw < 1) nw = 1;
         J.nwaves = (int)nw;
+        J.tall = tall ? 1 : 0;
         J.wave0 = (int)job_of_wave.size();
         for (long w = 0; w < nw; ++w) job_of_wave.push_back(j);
         doubles += (size_t)nw * J.nc * J.nc;
@@ -175,8 +185,9 @@ int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cu
     size_t skipm = 0;
     for (int kp = 0; kp < padm; ++kp) skipm += 16 * (4 - (kp >> 4));
     const size_t lds = sizeof(double) * (64 + 256 * 10 - skipm);
+
     long max_tiles = 1;
-    for (auto &J : jobs) max_tiles = std::max(max_tiles, (J.rows + 63) / 64);
+    for (auto &J : jobs) max_tiles = std::max(max_tiles, (J.rows + 63) / 64);  // (enough for either tile height)
     static size_t zeroed = 0;
     const size_t zneed = sizeof(int) * (size_t)(max_tiles + 1);
     int *zeros = static_cast<int *>(workspace(zneed, 31));
