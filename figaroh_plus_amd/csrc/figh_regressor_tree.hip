@@ -147,10 +147,20 @@ __device__ __forceinline__ void stream_zeros(const int lane, const int nvalid, d
             __builtin_amdgcn_make_buffer_rsrc(W + rowbase * ldw + c0, (short)0, 0x7fffffff, 0x00020000);
         const unsigned ch = (unsigned)w >> 1, total = (unsigned)nvalid * ch;
         const u32x4 z = {0u, 0u, 0u, 0u};
+        // (row, chunk) of a lane's store advance by a fixed step with a carry: additions only inside the loop (the division by
+        // multiplication per store cost three quarter-rate integer multiplies for every 16-byte store of a zero run)
+        unsigned row = __umulhi((unsigned)lane, magic2);
+        unsigned k = (unsigned)lane - row * ch;
+        unsigned off = row * ldw8 + 16u * k;
+        const unsigned dr = __umulhi(64u, magic2), dk = 64u - dr * ch;  // 64 = dr ch + dk
+        const unsigned doff = dr * ldw8 + 16u * dk, wrap = ldw8 - 16u * ch;
         for (unsigned id = (unsigned)lane; id < total; id += 64u) {
-            const unsigned row = __umulhi(id, magic2);
-            const unsigned k = id - row * ch;
-            __builtin_amdgcn_raw_buffer_store_b128(z, rs, row * ldw8 + 16u * k, 0u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(z, rs, off, 0u, 0);
+            k += dk;
+            off += doff;
+            const bool carry = k >= ch;
+            k -= carry ? ch : 0u;
+            off += carry ? wrap : 0u;
         }
     } else {
         const unsigned total = (unsigned)nvalid * (unsigned)w;
