@@ -10,7 +10,7 @@ c=sqlite3.connect(db)
 tabs=[r[0] for r in c.execute("select name from sqlite_master where type='table'")]
 kd=[t for t in tabs if "kernel_dispatch" in t][0]; ks=[t for t in tabs if "info_kernel_symbol" in t][0]
 rows=list(c.execute(f"select d.start,d.end,s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-t0=rows[0][0]; prev=None; LAST=(rows[-1][1]-t0)/1e6-15.5
+t0=rows[0][0]; prev=None; LAST=(rows[-1][1]-t0)/1e6-float("${2:-15.5}")
 for st,en,name in rows:
     gap=(st-prev)/1e6 if prev else 0
     if (st-t0)/1e6 > LAST:
