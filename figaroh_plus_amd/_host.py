@@ -84,3 +84,18 @@ def singular_values_batch(R):
     with ThreadPoolExecutor(workers) as pool:
         list(pool.map(lambda k: work(bounds[k], bounds[k + 1]), range(workers)))
     return out
+
+
+def relative_percent(sigma, phi):
+    """100 sigma_i / |phi_i| rounded to two decimals -- the reference's std% (identification_tools.py:226-232,
+    examples/staubli_TX40/identification.py:342-346).  An estimate that rounds to exactly zero (the scripts round phi to six
+    decimals first) gives ``inf`` there as well -- NumPy's division by zero, with a RuntimeWarning per element; here the same
+    ``inf`` is returned on purpose and without the warning: "this parameter's relative uncertainty is unbounded" is what the
+    essential-parameter loop (:354-399) acts on when it drops the parameter with the largest std%."""
+    import numpy as np
+    sigma = np.asarray(sigma, dtype=np.float64)
+    phi = np.abs(np.asarray(phi, dtype=np.float64))
+    out = np.full(sigma.shape, np.inf)
+    np.divide(100.0 * sigma, phi, out=out, where=phi != 0.0)
+    out[(phi == 0.0) & (sigma == 0.0)] = np.nan  # (0 / 0, as NumPy has it)
+    return np.round(out, 2)

@@ -75,13 +75,15 @@ void *workspace(size_t bytes, int slot);
 
 }  // namespace figh
 
-// internal (not part of include/figh.h): level 0 of the TSQR only, see figh_linalg.hip
-extern "C" int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
-                                const double *d_tau, const double *h_block_weight, int nblocks, double *d_tri_out,
-                                int64_t capacity, int64_t *count_out, double **ws_out);
-extern "C" int64_t figh_tsqr_level0_capacity(int nc);
-extern "C" int figh_tsqr_hint_begin(const int32_t *h_first_col, int nfirst, int64_t rows, int n, int nc);
-extern "C" void figh_tsqr_hint_end(void);
+// internal (not part of include/figh.h, not exported by libfigh.so: hidden visibility): level 0 of the TSQR only, see
+// figh_linalg.hip
+#define FIGH_INTERNAL extern "C" __attribute__((visibility("hidden")))
+FIGH_INTERNAL int figh_tsqr_level0(const double *d_W, int64_t rows, int64_t ldw, const int32_t *d_col_idx, int n,
+                                   const double *d_tau, const double *h_block_weight, int nblocks, double *d_tri_out,
+                                   int64_t capacity, int64_t *count_out, double **ws_out);
+FIGH_INTERNAL int64_t figh_tsqr_level0_capacity(int nc);
+FIGH_INTERNAL int figh_tsqr_hint_begin(const int32_t *h_first_col, int nfirst, int64_t rows, int n, int nc);
+FIGH_INTERNAL void figh_tsqr_hint_end(void);
 
 namespace figh {
 

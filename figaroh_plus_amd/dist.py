@@ -28,34 +28,175 @@ def shard_range(n_total, rank, world_size):
     return lo, hi
 
 
+def _wire_encode(obj, out):
+    """Tagged, self-describing encoding of the few value types the control plane carries (None, bool, int, float, str,
+    bytes, list / tuple, dict with string keys, float64 / int64 arrays).  Data only: decoding never constructs anything but these types -- the frames
+    of a TCP peer are not unpickled."""
+    import struct
+
+    if obj is None:
+        out += b"N"
+    elif isinstance(obj, (bool, np.bool_)):
+        out += b"T" if obj else b"F"
+    elif isinstance(obj, (int, np.integer)):
+        out += b"i" + struct.pack("<q", int(obj))
+    elif isinstance(obj, (float, np.floating)):
+        out += b"d" + struct.pack("<d", float(obj))
+    elif isinstance(obj, str):
+        raw = obj.encode("utf-8")
+        out += b"s" + struct.pack("<Q", len(raw)) + raw
+    elif isinstance(obj, (bytes, bytearray)):
+        out += b"b" + struct.pack("<Q", len(obj)) + bytes(obj)
+    elif isinstance(obj, (list, tuple)):
+        out += (b"l" if isinstance(obj, list) else b"t") + struct.pack("<Q", len(obj))
+        for item in obj:
+            _wire_encode(item, out)
+    elif isinstance(obj, dict):
+        out += b"m" + struct.pack("<Q", len(obj))
+        for key, item in obj.items():
+            if not isinstance(key, str):
+                raise TypeError("control plane: dictionary keys are strings")
+            _wire_encode(key, out)
+            _wire_encode(item, out)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype == np.float64:
+            code = b"D"
+        elif obj.dtype == np.int64:
+            code = b"I"
+        else:
+            raise TypeError("control plane: arrays travel as float64 or int64, not %s" % obj.dtype)
+        arr = np.ascontiguousarray(obj)
+        out += b"a" + code + struct.pack("<B", arr.ndim) + struct.pack("<%dQ" % arr.ndim, *arr.shape) + arr.tobytes()
+    else:
+        raise TypeError("control plane cannot carry a %s" % type(obj).__name__)
+
+
+def _wire_decode(buf, pos=0, depth=0):
+    import struct
+
+    if depth > 8:
+        raise ValueError("control plane frame nested too deeply")
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag in (b"T", b"F"):
+        return tag == b"T", pos
+    if tag == b"i":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"d":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"s", b"b"):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if pos + n > len(buf):
+            raise ValueError("control plane frame truncated")
+        raw = bytes(buf[pos:pos + n])
+        return (raw.decode("utf-8") if tag == b"s" else raw), pos + n
+    if tag in (b"l", b"t"):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf):
+            raise ValueError("control plane frame: impossible element count")
+        items = []
+        for _ in range(n):
+            item, pos = _wire_decode(buf, pos, depth + 1)
+            items.append(item)
+        return (items if tag == b"l" else tuple(items)), pos
+    if tag == b"m":
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf):
+            raise ValueError("control plane frame: impossible element count")
+        items = {}
+        for _ in range(n):
+            key, pos = _wire_decode(buf, pos, depth + 1)
+            if not isinstance(key, str):
+                raise ValueError("control plane frame: dictionary key")
+            items[key], pos = _wire_decode(buf, pos, depth + 1)
+        return items, pos
+    if tag == b"a":
+        code = buf[pos:pos + 1]
+        if code not in (b"D", b"I"):
+            raise ValueError("control plane frame: unknown array type")
+        ndim = buf[pos + 1]
+        pos += 2
+        if ndim > 4:
+            raise ValueError("control plane frame: array rank")
+        shape = struct.unpack_from("<%dQ" % ndim, buf, pos)
+        pos += 8 * ndim
+        count = 1
+        for d in shape:
+            count *= d
+        nbytes = 8 * count
+        if pos + nbytes > len(buf):
+            raise ValueError("control plane frame truncated")
+        arr = np.frombuffer(buf, dtype=np.float64 if code == b"D" else np.int64, count=count, offset=pos).reshape(shape).copy()
+        return arr, pos + nbytes
+    raise ValueError("control plane frame: unknown tag %r" % tag)
+
+
 class SocketGroup:
     """A control plane without PyTorch: rank 0 listens, the others connect; every collective is a gather to rank 0 and a
-    broadcast back (pickled Python objects, length-prefixed).  For the handful of small messages of a run -- RCCL set-up,
-    barriers, and the host-staged exchange of column norms and triangles -- not for bulk data."""
+    broadcast back.  Frames are length-prefixed and carry plain data in a tagged encoding (``_wire_encode``: no pickle --
+    nothing a peer sends is ever executed).  With ``FIGH_COMM_SECRET`` in the environment (same value on every rank) every
+    frame is authenticated with HMAC-SHA256 and frames from anybody else are rejected.  For the handful of small messages
+    of a run -- RCCL set-up, barriers, and the host-staged exchange of column norms and triangles -- not for bulk data.
+
+    ``timeout`` bounds the rendezvous only (accept / connect / hello); once the group is formed the sockets block without a
+    limit: a rank may legitimately wait at a barrier for as long as its slowest peer computes."""
 
     PORT_OFFSET = 101  # MASTER_PORT itself belongs to the launcher's own store
+    MAX_FRAME = 1 << 30
 
-    def __init__(self, rank, world_size, addr, port, timeout=120.0):
+    def __init__(self, rank, world_size, addr, port, timeout=120.0, secret=None):
         import socket
         import time
 
         self.rank, self.world_size = int(rank), int(world_size)
+        if not 0 <= self.rank < self.world_size:
+            raise ValueError("rank %d outside [0, %d)" % (self.rank, self.world_size))
+        if secret is None:
+            secret = os.environ.get("FIGH_COMM_SECRET", "")
+        self._key = secret.encode("utf-8") if isinstance(secret, str) else bytes(secret)
         self._peers = []
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
             srv.listen(self.world_size)
-            srv.settimeout(timeout)
+            deadline = time.time() + timeout
             conns = {}
-            while len(conns) < self.world_size - 1:
-                c, _ = srv.accept()
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(timeout)
-                r = self._recv(c)
-                conns[int(r)] = c
-            srv.close()
+            try:
+                while len(conns) < self.world_size - 1:
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise TimeoutError("control plane: %d of %d ranks joined within %.0f s"
+                                           % (len(conns) + 1, self.world_size, timeout))
+                    srv.settimeout(left)
+                    c, _ = srv.accept()
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    c.settimeout(min(10.0, timeout))
+                    # a connection that does not introduce itself properly (stray client, wrong secret, rank out of range,
+                    # a rank that is already here) is dropped; the rendezvous goes on waiting for the real one
+                    try:
+                        hello = self._recv(c)
+                        if not (isinstance(hello, tuple) and len(hello) == 3 and hello[0] == "figh-hello"):
+                            raise ValueError("not a hello frame")
+                        r, w = hello[1], hello[2]
+                        if not (isinstance(r, int) and isinstance(w, int)) or w != self.world_size or not 1 <= r < w:
+                            raise ValueError("rank %r of %r" % (r, w))
+                        if r in conns:
+                            raise ValueError("rank %d joined twice" % r)
+                    except Exception:  # noqa: BLE001
+                        c.close()
+                        continue
+                    conns[r] = c
+            finally:
+                srv.close()
             self._peers = [conns[r] for r in range(1, self.world_size)]
+            for c in self._peers:
+                self._send(c, ("figh-welcome", self.world_size))
         else:
             deadline = time.time() + timeout
             while True:
@@ -68,25 +209,35 @@ class SocketGroup:
                     time.sleep(0.05)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             c.settimeout(timeout)
-            self._send(c, self.rank)
+            self._send(c, ("figh-hello", self.rank, self.world_size))
+            ack = self._recv(c)
+            if ack != ("figh-welcome", self.world_size):
+                raise ConnectionError("control plane: unexpected answer from rank 0")
             self._peers = [c]
+        for c in self._peers:
+            c.settimeout(None)
 
     @classmethod
     def from_env(cls):
         return cls(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), os.environ.get("MASTER_ADDR", "127.0.0.1"),
                    int(os.environ["MASTER_PORT"]) + cls.PORT_OFFSET)
 
-    @staticmethod
-    def _send(c, obj):
-        import pickle
+    def _mac(self, data):
+        import hashlib
+        import hmac
+
+        return hmac.new(self._key, data, hashlib.sha256).digest() if self._key else b""
+
+    def _send(self, c, obj):
         import struct
 
-        data = pickle.dumps(obj, protocol=4)
-        c.sendall(struct.pack("<Q", len(data)) + data)
+        data = bytearray()
+        _wire_encode(obj, data)
+        data = bytes(data)
+        c.sendall(struct.pack("<Q", len(data)) + self._mac(data) + data)
 
-    @staticmethod
-    def _recv(c):
-        import pickle
+    def _recv(self, c):
+        import hmac
         import struct
 
         def exactly(n):
@@ -98,7 +249,16 @@ class SocketGroup:
                 buf += chunk
             return bytes(buf)
         (n,) = struct.unpack("<Q", exactly(8))
-        return pickle.loads(exactly(n))
+        if n > self.MAX_FRAME:
+            raise ValueError("control plane frame of %d bytes refused" % n)
+        mac = exactly(32) if self._key else b""
+        data = exactly(n)
+        if self._key and not hmac.compare_digest(mac, self._mac(data)):
+            raise ConnectionError("control plane frame failed authentication")
+        obj, pos = _wire_decode(data)
+        if pos != len(data):
+            raise ValueError("control plane frame: trailing bytes")
+        return obj
 
     def all_gather_object(self, obj):
         """[obj of rank 0, obj of rank 1, ...] on every rank."""

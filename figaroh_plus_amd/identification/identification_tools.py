@@ -10,7 +10,7 @@ import operator
 import numpy as np
 
 from .. import _lib
-from .._host import host_tail
+from .._host import host_tail, relative_percent
 from ..device import GpuMatrix, to_device, vector_to_device
 from ..tools.qrdecomposition import rfactor
 
@@ -137,10 +137,7 @@ def relative_stdev(W_b, phi_b, tau):
     R_inv = np.linalg.inv(R)
     C_x = sig_ro_sqr * (R_inv @ R_inv.T)
     std_x_sqr = np.diag(C_x)
-    std_xr = np.zeros(std_x_sqr.shape[0])
-    for i in range(std_x_sqr.shape[0]):
-        std_xr[i] = np.round(100 * np.sqrt(std_x_sqr[i]) / np.abs(phi_b[i]), 2)
-    return std_xr
+    return relative_percent(np.sqrt(std_x_sqr), phi_b)  # (an estimate of exactly zero: inf, like the reference's division)
 
 
 def block_residual_sqnorms(tau_meas, tau_est, nblocks):
@@ -207,7 +204,7 @@ def weighted_least_squares_blocks(W_b, tau, phi_b, nblocks, return_details=False
     phi = np.around(np.linalg.solve(R, z), 6)
     R_inv = np.linalg.inv(R)
     C_X = R_inv @ R_inv.T
-    std = np.round(100 * np.sqrt(np.diag(C_X)) / np.abs(phi), 2)
+    std = relative_percent(np.sqrt(np.diag(C_X)), phi)
     if return_details:  # the per-joint variances and the weighted triangle of [W_b tau]: what essential_parameters takes
         if np.isscalar(nblocks):
             sig2_joint = sq / (Wd.rows // int(nblocks))
@@ -425,7 +422,8 @@ def essential_parameters(R_ols, R_wls, params_base, std_xr, ratio_essential, row
     solution -- follows from the re-triangularised r x r remainder: the rows of W are never read again.
 
     While ``max(std) >= ratio_essential * min(std)``: drop the parameter with the largest std% (``np.isclose`` match, as in
-    the script: more than one match raises ValueError like the script's tuple unpacking), OLS (6 decimals) + its std%,
+    the script; a TIE -- two parameters whose 2-decimal std% are both "the largest", two ``inf`` included -- raises
+    TypeError exactly where the script's ``int(i)`` does, instead of silently dropping the first), OLS (6 decimals) + its std%,
     WLS (6 decimals) + its std%.  ``rows_total`` = len(tau_) (the row count relative_stdev divides by; without it
     std_e_ols is left out).  Returns a dict: params_essential, idx_essential (positions in params_base), phi_e_ols,
     std_e_ols, phi_e_wls, std_e_wls, iterations."""
@@ -441,6 +439,9 @@ def essential_parameters(R_ols, R_wls, params_base, std_xr, ratio_essential, row
     it = 0
     while not (std_e.max() < ratio_essential * std_e.min()):
         (i,) = np.where(np.isclose(std_e, std_e.max()))
+        if i.size != 1:  # the script: int(i) of a longer array
+            raise TypeError("only length-1 arrays can be converted to Python scalars (essential_parameters: %d parameters "
+                            "tie for the largest std%% %r)" % (i.size, float(std_e.max())))
         del names[int(i[0])]
         del keep[int(i[0])]
         k = len(keep)
@@ -454,10 +455,10 @@ def essential_parameters(R_ols, R_wls, params_base, std_xr, ratio_essential, row
             res2 = float(np.sum((Ro[:k, :k] @ phi_o - Ro[:k, k]) ** 2) + (Ro[k, k] ** 2 if Ro.shape[0] > k else 0.0))
             Ri = np.linalg.inv(Ro[:k, :k])
             C = res2 / (rows_total - k) * (Ri @ Ri.T)
-            out["std_e_ols"] = np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi_o), 2)
+            out["std_e_ols"] = relative_percent(np.sqrt(np.diag(C)), phi_o)
         Rwi = np.linalg.inv(Rw[:k, :k])
         phi_w = np.around(np.linalg.solve(Rw[:k, :k], Rw[:k, k]), 6)
-        std_e = np.round(100 * np.sqrt(np.einsum("ij,ij->i", Rwi, Rwi)) / np.abs(phi_w), 2)
+        std_e = relative_percent(np.sqrt(np.einsum("ij,ij->i", Rwi, Rwi)), phi_w)
         out["phi_e_wls"], out["std_e_wls"] = phi_w, std_e.copy()
         it += 1
     out.update(params_essential=names, idx_essential=keep, iterations=it)

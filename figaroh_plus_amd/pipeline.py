@@ -55,6 +55,7 @@ class _View:
         self.ptr = base.ptr + int(byte_offset)
 
 
+from ._host import relative_percent as _relative_percent
 from ._host import single_threaded_blas as _single_threaded_blas
 
 
@@ -90,7 +91,7 @@ class IdentificationPipeline:
         # (figh_regressor_tsqr_fused) over the kept-column list of the previous pass -- every 64-row tile of W is factored
         # while it is still in LDS, W is written but not read back.  The list is verified against the norms the pass produces;
         # a pass whose kept set changed falls back to the two launches below (and learns the new list).
-        self.fuse = bool(fuse)
+        self.fuse = self._fuse_requested = bool(fuse)
         self.null_pivots = bool(null_pivots)
         self._fused_kept = None
         self.fused_passes = 0
@@ -161,6 +162,16 @@ class IdentificationPipeline:
                 self.chunk_samples = max(64, (int(self.chunk_samples) // 64) * 64)  # chunks start on tile boundaries
         self.N, self.d_q, self.d_v, self.d_a, self.d_tau = N, d_q, d_v, d_a, d_tau
         self.W = None
+        # Fused launch: eligibility is decided again for every sample set (a set that was too small to fuse says nothing
+        # about the next one), and under a collective exchange from a value all ranks agree on -- the fused launch needs at
+        # least 4096 local samples, and ranks whose shards straddle that size must not take different paths through the
+        # pass: one rank that cannot fuse keeps every rank on the two-launch path.
+        self.fuse = self._fuse_requested
+        ex = self.exchange
+        if self.fuse and getattr(ex, "collective", False) and ex.world_size > 1:
+            flag = _lib.DeviceArray.from_host(np.array([0.0 if N >= 4096 else 1.0]))
+            self.fuse = float(np.asarray(ex.sum_columns(flag, 1)).reshape(-1)[0]) == 0.0
+            flag.free()
 
     def _flags(self):
         """(mode, flags, ft_mask) of this pipeline's regressor calls, including the layout of its input arrays."""
@@ -456,7 +467,7 @@ class IdentificationPipeline:
         if not _lib.regressor_tsqr_fused(handle, flags, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, self._d_colsq,
                                          d_kept, n, self.d_tau, self.tol_qr if local else -1.0,
                                          self._d_rows if local else self._d_R):
-            self.fuse = False  # (this shape never fuses: do not ask again)
+            self.fuse = False  # (this shape does not fuse: not asked again until the next set_samples)
             return None
         ex.sum_columns_device(self._d_colsq, ncols)
         _lib.select_columns(self._d_colsq, ncols, self.tol_e, 14, self._d_sel)
@@ -518,7 +529,12 @@ class IdentificationPipeline:
         mode, _, _ = self._flags()
         nblocks = self.robot.model.nv if mode == _lib.MODE_JOINT_TORQUE else 6
         rows_blk = W.rows // nblocks
-        d_r2 = _lib.DeviceArray((nblocks,), np.float64)
+        # [residual norms of the nblocks row blocks | this rank's rows per block]: one sum over the ranks gives both -- the
+        # shards of a run need not be equally long (dist.shard_range), so the divisor is the summed row count, not
+        # rows_blk * world_size
+        d_r2 = _lib.DeviceArray((nblocks + 1,), np.float64)
+        _rows = np.array([float(rows_blk)])
+        _lib.check(_lib.load().figh_memcpy_h2d(d_r2.ptr + 8 * nblocks, _rows.ctypes.data, 8))
         d_Rw = _lib.DeviceArray(((nb_par + 1) * (nb_par + 1),), np.float64)
         kept = np.flatnonzero(self._kept_cache[0])
         if getattr(self, "_have_block_tri", False):
@@ -530,8 +546,8 @@ class IdentificationPipeline:
             v[base] = phi_b
             v[n] = -1.0
             _lib.block_rows_residuals(tri, row_off, nc, _lib.DeviceArray.from_host(v), d_r2)
-            r2 = ex.sum_columns(d_r2, nblocks)
-            sig2 = r2 / (rows_blk * ex.world_size)
+            r2 = np.asarray(ex.sum_columns(d_r2, nblocks + 1))
+            sig2 = r2[:nblocks] / r2[nblocks]
             d_cols = _lib.DeviceArray.from_host(np.r_[base, n].astype(np.int32))
             _lib.tsqr(tri, int(row_off[-1]), nc, d_cols, nb_par + 1, None, np.repeat(1.0 / np.sqrt(sig2), counts), d_Rw)
             source = "per-row-block triangles"
@@ -543,8 +559,8 @@ class IdentificationPipeline:
             _lib.matvec(W.buf, W.rows, W.ld, d_cols, nb_par, _lib.DeviceArray.from_host(phi_b), d_est)
             _lib.block_sqnorm(self.d_tau, d_est, W.rows, nblocks, d_r2)
             d_est.free()
-            r2 = ex.sum_columns(d_r2, nblocks)
-            sig2 = r2 / (rows_blk * ex.world_size)
+            r2 = np.asarray(ex.sum_columns(d_r2, nblocks + 1))
+            sig2 = r2[:nblocks] / r2[nblocks]
             _lib.tsqr(W.buf, W.rows, W.ld, d_cols, nb_par, self.d_tau, 1.0 / np.sqrt(sig2), d_Rw)
             source = "second pass over W"
         if getattr(ex, "collective", True) and ex.world_size > 1:
@@ -564,7 +580,7 @@ class IdentificationPipeline:
             R_inv, info = _dtrtri(np.ascontiguousarray(R))
             if info != 0:
                 raise np.linalg.LinAlgError("Singular matrix")
-            std = np.round(100 * np.sqrt(np.einsum("ij,ij->i", R_inv, R_inv)) / np.abs(phi), 2)
+            std = _relative_percent(np.sqrt(np.einsum("ij,ij->i", R_inv, R_inv)), phi)  # (phi_i == 0: inf, as in the script)
         out["phi_wls"], out["std_wls"], out["sigma2_joint"], out["wls_source"] = phi, std, sig2, source
         return out
 

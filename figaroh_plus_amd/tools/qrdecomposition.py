@@ -88,9 +88,11 @@ def _base_columns(Wd, idx, keep_on_device=False):
 
 
 @host_tail
-def get_baseIndex(W_e, params_r, tol_qr=TOL_QR):
-    """Indices of the linearly independent columns (qrdecomposition.py:274-296)."""
-    R = rfactor(W_e, tol_qr=tol_qr)
+def get_baseIndex(W_e, params_r, tol_qr=TOL_QR, null_pivots=True):
+    """Indices of the linearly independent columns (qrdecomposition.py:274-296).  ``null_pivots=False`` (not a reference
+    argument): plain Householder steps on every column, the reference's LAPACK arithmetic step for step, instead of the
+    null-pivot rule of include/figh.h (columns that are zero to tol_qr / 64 below the triangle skip their reflector)."""
+    R = rfactor(W_e, tol_qr=tol_qr if null_pivots else None)
     idx_base, _ = _select(np.diag(R), params_r, tol_qr)
     return tuple(idx_base)
 
@@ -102,10 +104,10 @@ def build_baseRegressor(W_e, idx_base):
 
 
 @host_tail
-def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
-    """(W_b, params_base, idx_base) -- qrdecomposition.py:190-271."""
+def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR, null_pivots=True):
+    """(W_b, params_base, idx_base) -- qrdecomposition.py:190-271.  ``null_pivots``: see :func:`get_baseIndex`."""
     Wd, on_dev = to_device(W_e)
-    R = rfactor(Wd, tol_qr=tol_qr)
+    R = rfactor(Wd, tol_qr=tol_qr if null_pivots else None)
     idx_base, idx_regroup = _select(np.diag(R), params_r, tol_qr)
     R1, R2, _ = _regroup(R, idx_base, idx_regroup, False)
     with single_threaded_blas():  # n x n host work: see _host.py
@@ -117,10 +119,11 @@ def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR):
 
 
 @host_tail
-def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR):
-    """(W_b, base_parameters, params_base, phi_b[, phi_std]) -- qrdecomposition.py:89-187."""
+def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR, null_pivots=True):
+    """(W_b, base_parameters, params_base, phi_b[, phi_std]) -- qrdecomposition.py:89-187.  ``null_pivots``: see
+    :func:`get_baseIndex`."""
     Wd, on_dev = to_device(W_e)
-    R = rfactor(Wd, tau=tau, tol_qr=tol_qr)
+    R = rfactor(Wd, tau=tau, tol_qr=tol_qr if null_pivots else None)
     n = len(params_r)
     assert R.shape[0] == n + 1, "params_r does not have same length with R"
     idx_base, idx_regroup = _select(np.diag(R)[:n], params_r, tol_qr)

@@ -80,11 +80,18 @@ int figh_host_wait_mode(int blocking);
  * the diagonal is <= tol -- sqrt(R_kk^2 + |x|^2) <= tol for the tile's part x of the column -- gets H = I (LAPACK dlarfg's
  * rule for an exactly zero x, with a threshold): its norm is folded into R_kk, the column leaves the tile, no reflector
  * is formed and no trailing update is made.  R_kk therefore carries the running residual norm of the column and the test
- * includes it, so that over ALL the rows of a matrix at most tol of a column's norm is ever folded: R is the exact R
- * factor of W + E with |E[:, k]| <= tol for such columns, E = 0 elsewhere.  The linearly dependent columns of a regressor
- * (qrdecomposition.py:208-221: |R_kk| <= tol_qr, 27 % of the kept columns of UR10 and 29 % of TALOS) are such columns in
- * every tile -- their residual is rounding noise -- and cost a norm instead of a column step.  tol = 0 (the default):
- * exact zeros only.  The pipeline and the qrdecomposition mirrors set tol_qr / 64.  Process-wide, takes effect at the
+ * includes it, so that INSIDE ONE LEVEL-0 TRIANGLE at most tol of a column's norm is ever folded.  Every level-0 triangle
+ * -- one per wave (register-tile kernel), per workgroup (blocked kernel), per consumer wave (fused launch) and per sample
+ * chunk of a streamed run -- starts from R_kk = 0 and makes the test on its own rows; the merge levels fold nothing.  With
+ * T level-0 triangles R is therefore the exact R factor of W + E with |E[:, k]|_2 <= sqrt(T) tol for such columns (the
+ * folded parts lie in disjoint rows), E = 0 elsewhere: T = 1536 for the fused UR10 launch, 512 for the blocked kernel,
+ * i.e. up to 0.35 - 0.6 tol_qr at tol = tol_qr / 64 -- reached only by a column whose residual really is that large in
+ * every triangle, and even then |R_kk| itself is exact (the norm moves into R_kk, it is not dropped); what E perturbs is
+ * the component of the LATER columns along that direction.  The linearly dependent columns of a regressor
+ * (qrdecomposition.py:208-221: |R_kk| <= tol_qr, 27 % of the kept columns of UR10 and 29 % of TALOS) are null in every
+ * tile -- their residual is rounding noise, 1e-13 .. 1e-12 -- and cost a norm instead of a column step.  tol = 0 (the
+ * default): exact zeros only.  The pipeline and the qrdecomposition mirrors set tol_qr / 64 unless told otherwise
+ * (null_pivots=False: plain Householder, the reference's arithmetic step for step).  Process-wide, takes effect at the
  * next launch. */
 int figh_tsqr_null_pivot_tol(double tol);
 /* PCI bus id ("0000:c1:00.0") of HIP device `device`: the physical device a rank drives, whatever logical index the

@@ -390,7 +390,8 @@ def relative_stdev(W_b, phi_b, tau):
     phi_b = np.asarray(phi_b, dtype=float)
     sig2 = np.linalg.norm(tau - W_b @ phi_b) ** 2 / (W_b.shape[0] - phi_b.shape[0])
     C = sig2 * np.linalg.inv(W_b.T @ W_b)
-    return np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi_b), 2)
+    with np.errstate(divide="ignore", invalid="ignore"):  # (phi_i == 0: inf, as the reference's scalar division gives)
+        return np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi_b), 2)
 
 
 def wls_script(W_b, tau, phi_b, row_counts):
@@ -404,7 +405,8 @@ def wls_script(W_b, tau, phi_b, row_counts):
         a += n
     C = np.linalg.inv(W_b.T @ (W_b * w[:, None]))
     phi = np.around(C @ (W_b.T @ (w * tau)), 6)
-    std = np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi), 2)
+    with np.errstate(divide="ignore", invalid="ignore"):  # (phi_i == 0: inf, as the script's scalar division gives)
+        std = np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi), 2)
     return phi, std
 
 
@@ -426,7 +428,8 @@ def essential_script(W_b, tau, params_base, std_xr, sig_ro_joint, row_counts, ra
         std_e_ols = relative_stdev(W_ess, phi_e_ols, tau)
         C = np.linalg.inv(W_ess.T @ (W_ess * w[:, None]))
         phi_e_wls = np.around(C @ (W_ess.T @ (w * tau)), 6)
-        std_e = np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi_e_wls), 2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            std_e = np.round(100 * np.sqrt(np.diag(C)) / np.abs(phi_e_wls), 2)
         out.update(phi_e_ols=phi_e_ols, std_e_ols=std_e_ols, phi_e_wls=phi_e_wls, std_e_wls=std_e.copy())
         out["iterations"] += 1
     out["params_essential"] = names

@@ -262,3 +262,116 @@ def test_socket_rendezvous_needs_no_torch(tmp_path):
         assert np.array(r["stack"]).shape == (world, 3, 3) and [s[0][0] for s in r["stack"]] == [0.0, 1.0, 2.0]
         assert r["objs"] == [{"rank": k} for k in range(world)] and r["top"] == "from %d" % (world - 1)
         assert not r["torch_loaded"]
+
+
+def test_control_plane_codec_is_data_only():
+    """The socket control plane carries tagged plain data (no pickle.loads on bytes from a TCP peer): the
+    value types of a run round-trip, anything else is refused when ENCODING, and a pickle payload does not decode."""
+    import pickle
+    from figaroh_plus_amd import dist as fd
+
+    objs = [None, True, 3, -1.5, "why", b"\x00\x01id", (True, "", ("host", "0000:05:00.0")), [b"x" * 128, ""],
+            {"rank": 2, "t": [1.0, 2.0]}, np.arange(12.0).reshape(3, 4), np.arange(5, dtype=np.int64)]
+    for o in objs:
+        buf = bytearray()
+        fd._wire_encode(o, buf)
+        back, pos = fd._wire_decode(bytes(buf))
+        assert pos == len(buf)
+        if isinstance(o, np.ndarray):
+            assert back.dtype == o.dtype and np.array_equal(back, o)
+        else:
+            assert back == o and type(back) is type(o)
+    with pytest.raises(TypeError):
+        fd._wire_encode(object(), bytearray())
+    with pytest.raises(TypeError):
+        fd._wire_encode(np.zeros(3, dtype=np.float32), bytearray())
+    with pytest.raises(ValueError):
+        fd._wire_decode(pickle.dumps({"rank": 1}, protocol=4))
+    with pytest.raises(ValueError):
+        fd._wire_decode(b"s" + (1 << 40).to_bytes(8, "little") + b"abc")  # length beyond the frame
+    assert "pickle" not in open(fd.__file__).read().split('"""', 2)[2].replace("no pickle", "").replace("not unpickled", "")
+
+
+def _rendezvous_worker(rank, world, port, out_dir, secret):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from figaroh_plus_amd import dist as fd
+
+    g = fd.SocketGroup(rank, world, "127.0.0.1", port, timeout=30.0, secret=secret)
+    got = g.all_gather_object(rank * 10)
+    g.barrier()
+    with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+        f.write(repr(got))
+    g.close()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("secret", ["", "s3cret"])
+def test_socket_rendezvous_rejects_strangers(tmp_path, secret):
+    """Rank 0 validates who joins: a stray connection that sends garbage, a frame with a wrong secret, a rank out of range and
+    a duplicate rank are dropped and the rendezvous completes with the real peers (before: KeyError / overwritten socket
+    and a 120 s hang)."""
+    import multiprocessing as mp
+    import struct
+    import time
+    from figaroh_plus_amd import dist as fd
+
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    world = 3
+    p0 = ctx.Process(target=_rendezvous_worker, args=(0, world, port, str(tmp_path), secret))
+    p0.start()
+
+    def connect():
+        deadline = time.time() + 20
+        while True:
+            try:
+                return socket.create_connection(("127.0.0.1", port), timeout=5.0)
+            except OSError:
+                assert time.time() < deadline
+                time.sleep(0.05)
+
+    def frame(obj, key):
+        import hashlib
+        import hmac
+        data = bytearray()
+        fd._wire_encode(obj, data)
+        data = bytes(data)
+        mac = hmac.new(key.encode(), data, hashlib.sha256).digest() if key else b""
+        return struct.pack("<Q", len(data)) + mac + data
+
+    strays = []
+    c = connect()
+    c.sendall(b"GET / HTTP/1.0\r\n\r\n")  # not a frame at all
+    strays.append(c)
+    c = connect()
+    c.sendall(frame(("figh-hello", 7, world), secret))  # rank out of range
+    strays.append(c)
+    c = connect()
+    c.sendall(frame(("figh-hello", 1, world), secret + "x"))  # wrong secret (or, without one, an unauthenticated extra MAC)
+    strays.append(c)
+    # rank 1 is played by this process, frame by frame, so that the duplicate is known to arrive after the real one
+    # (rank 0 accepts connections in the order they were established and reads each hello before the next accept)
+    real1 = connect()
+    real1.sendall(frame(("figh-hello", 1, world), secret))
+    c = connect()
+    c.sendall(frame(("figh-hello", 1, world), secret))  # rank 1 a second time
+    strays.append(c)
+    p2 = ctx.Process(target=_rendezvous_worker, args=(2, world, port, str(tmp_path), secret))
+    p2.start()
+    peer = fd.SocketGroup.__new__(fd.SocketGroup)
+    peer._key = secret.encode()
+    real1.settimeout(60)
+    assert peer._recv(real1) == ("figh-welcome", world)
+    peer._send(real1, 10)
+    assert peer._recv(real1) == [0, 10, 20]
+    peer._send(real1, None)  # the barrier
+    assert peer._recv(real1) == [None, None, None]
+    for p in (p0, p2):
+        p.join(60)
+        assert p.exitcode == 0
+    real1.close()
+    for c in strays:
+        c.close()
+    for r in (0, 2):
+        assert open(tmp_path / ("r%d.txt" % r)).read() == "[0, 10, 20]"
