@@ -152,7 +152,10 @@ CONFIGS = {  # BASELINE.json configs[1..4]: (golden fixture, model, samples in t
     "cfg2": ("cfg2_ur10", "ur10", 1_000_000, None),
     "cfg3": ("cfg3_tiago", "tiago", 1_000_000, None),
     "cfg4": ("cfg4_talos", "talos", 4_000_000, None),
-    "cfg5": ("cfg5_human", "human", 10_000_000, 2_500_000),  # (67 GB of W per chunk; 500 000: +12 % step time, tools/chunk_sweep.sh)
+    # cfg5: W RESIDENT since round 5 -- the link-compact layout (21 massless links of the human model have no columns: 146 GB
+    # for 6e7 rows instead of 307 GB) fits HBM in one piece: 122 ms against 131 ms streamed in chunks of 2.5e6 samples
+    # (--chunk-samples 2500000; 151 ms in round 4 with 67 GB link-padded chunks)
+    "cfg5": ("cfg5_human", "human", 10_000_000, None),
 }
 
 
@@ -168,13 +171,13 @@ def main():
                          "(default for cfg3-5)")
     ap.add_argument("--samples", type=int, default=None, help="samples per GPU (weak) / in total (strong)")
     ap.add_argument("--chunk-samples", type=int, default=None,
-                    help="cfg5: samples per chunk of the streamed pass (default: the config's 2 500 000)")
+                    help="cfg5: stream the samples in chunks of this size (figh_regressor_tsqr) instead of keeping W resident")
     ap.add_argument("--cpu-samples", type=int, default=None,
                     help="samples of the CPU baseline legs (default: 300000 for cfg2, 20000 for cfg3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch", "host"],
                     help="rccl: device buffers over RCCL / xGMI; torch / host: host-staged through the control plane")
-    ap.add_argument("--rendezvous", default="torch", choices=["torch", "socket"],
+    ap.add_argument("--rendezvous", default="socket", choices=["torch", "socket"],
                     help="control plane of a multi-rank run (RCCL id exchange, barriers, max over ranks): torch.distributed "
                          "(gloo) or figaroh_plus_amd.dist.SocketGroup (standard library only: no PyTorch in the process)")
     ap.add_argument("--placement-trials", type=int, default=1,
@@ -191,6 +194,10 @@ def main():
                          "in joint-torque mode, cfg3) = row block j as its own N x 16 |subtree_j| matrix: only the window of a "
                          "row that can be non-zero is stored, written and read, every stored byte in every pass "
                          "(FIGH_FLAG_COMPACT_BLOCKS).  auto = block-compact where it applies; config.w_layout says which")
+    ap.add_argument("--active-joints", action="store_true",
+                    help="cfg3: only the row blocks of the eight joints that carry measurements in the TIAGo script (torso_lift, "
+                         "arm_1..7: examples/tiago/identification.py:406-424) are stored and factored "
+                         "(IdentificationPipeline(row_blocks=act_idxv)); the elimination still uses the norms of all 24 blocks")
     ap.add_argument("--no-wls", action="store_true",
                     help="cfg3: leave the weighted least squares (examples/staubli_TX40/identification.py:305-346) out of the "
                          "timed step (default: included, as BASELINE configs[2] says \"WLS solve\")")
@@ -237,7 +244,7 @@ def main():
             group.barrier()
 
     fixture, model_name, n_config, chunk = CONFIGS[args.config]
-    if args.chunk_samples and chunk:
+    if args.chunk_samples and args.config == "cfg5":
         chunk = args.chunk_samples
     scaling = args.scaling or ("weak" if args.config == "cfg2" else "strong")
     with open(os.path.join(ROOT, "tests", "golden", fixture + ".json")) as f:
@@ -257,7 +264,14 @@ def main():
         q, v, a = (rng.uniform(-6, 6, (N, 6)) for _ in range(3))
     else:
         q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
+    row_blocks = None
+    if args.active_joints:
+        if args.config != "cfg3":
+            raise SystemExit("--active-joints is the TIAGo script's variant (cfg3)")
+        names = ["torso_lift_joint"] + ["arm_%d_joint" % k for k in range(1, 8)]
+        row_blocks = [robot.model.joints[robot.model.getJointId(n)].idx_v for n in names]
     pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
+                                  row_blocks=row_blocks,
                                   chunk_samples=chunk, placement_trials=args.placement_trials,
                                   structural_zeros=args.structural_zeros,
                                   w_layout="dense" if args.w_layout == "dense" else "block-compact", fuse=not args.no_fuse,
@@ -301,7 +315,7 @@ def main():
     ok = out["idx_e"] == [int(x) for x in np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))["idx_e"]]
     if args.config != "cfg3":
         ok = ok and out["idx_base"] == meta_idx(meta) and out["params_base"] == meta["params_base"]
-    elif world == 1 and N == 1_000_000:
+    elif world == 1 and N == 1_000_000 and not args.active_joints:
         # cfg3 at the BASELINE size: the index set a LAPACK Householder TSQR of the oracle's W keeps for THESE samples
         # (tests/golden/cfg3_tiago_large.json, oracle/pin_cfg3_large.py: 185 base parameters -- six pivots of the golden's
         # dependent columns have grown past TOL_QR like sqrt(N))
@@ -315,6 +329,18 @@ def main():
         cnt, ms = _lib.profile_get(name)
         if cnt:
             kern[name] = {"launches": cnt, "avg_ms": ms / cnt}
+    # FIRST pass: what a script that calls the identification functions once pays (examples/ur10/identification.py:71-83) --
+    # the pipeline forgets everything it has learnt from earlier passes (kept-column set, counts, per-block lists; the HBM
+    # buffers stay allocated) and runs one pass; median of five.  Collective-safe: every rank forgets and runs.
+    first_times = []
+    fused_before = pipe.fused_passes
+    for _ in range(5):
+        pipe.forget()
+        barrier()
+        ts = time.perf_counter()
+        pipe.run(wls=wls)
+        first_times.append(time.perf_counter() - ts)
+    first_fused = pipe.fused_passes - fused_before
     # the small launches (merge levels, regrouped n x n factorisation, collectives) are timed in two extra,
     # untimed passes so that their event records do not sit in the timed region
     _lib.profile_enable(True, level=2)
@@ -355,6 +381,12 @@ def main():
             # reference's dense rows -- `achieved` / `frac` count the bytes this layout stores (every one of them is written
             # in every pass); the rate on the reference's dense bytes is kept beside them and is not a fraction of anything
             stored = 8 * (m.nq + 2 * m.nv) + 8 * float(pipe._compact[1].sum())
+            roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
+                                  "dense_bytes_per_sample": bytes_per_sample,
+                                  "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
+        if getattr(pipe, "_link_pos", None) is not None:
+            # link-compact W: links without entries (massless bodies) have no columns; same accounting as above
+            stored = 8 * (m.nq + 2 * m.nv) + 8 * rows_per_sample * 16.0 * int((pipe._link_pos >= 0).sum())
             roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
                                   "dense_bytes_per_sample": bytes_per_sample,
                                   "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
@@ -470,6 +502,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_median": 1e3 * float(np.median(step_times)),
             "ms_per_step_min": 1e3 * float(np.min(step_times)),
+            "ms_first_pass": 1e3 * float(np.median(first_times)),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -486,8 +519,10 @@ def main():
                                 " (WLS left out: --no-wls)"),
                     "cfg4": "BASELINE configs[3]: TALOS floating base, external-wrench regressor, %d samples in total "
                             "sharded over the GPUs, regressor (6N x 462, device-resident, link-padded) + blocked TSQR" % n_total,
-                    "cfg5": "BASELINE configs[4]: human whole-body, %d samples in total sharded over the GPUs, streamed in "
-                            "chunks of %s samples (W = 269 GB never exists in full)" % (n_total, chunk),
+                    "cfg5": "BASELINE configs[4]: human whole-body, %d samples in total sharded over the GPUs, %s" % (
+                        n_total, ("streamed in chunks of %s samples (W never exists in full)" % chunk) if chunk else
+                        "external-wrench regressor (6N x 560) device-resident in the link-compact layout (19 links with "
+                        "mass x 16 columns) + force / torque split TSQR"),
                 }[args.config],
                 "samples_this_rank": N, "samples_total": n_total, "columns": ncols, "kept_columns": n_kept,
                 "base_parameters": len(out["idx_base"]), "collective": xinfo["collective"], "ranks": world,
@@ -497,14 +532,19 @@ def main():
                 "w_placement": pipe.placement_report or {"trials": 1},
                 "w_layout": ("block-compact: row block j = N x 16 |subtree_j| (%.1f GB instead of %.1f GB)"
                              % (8e-9 * pipe.N * float(pipe._compact[1].sum()), 8e-9 * pipe.W.rows * pipe.W.ld))
-                if getattr(pipe, "_compact", None) is not None else "dense",
+                if getattr(pipe, "_compact", None) is not None else (
+                    "link-compact: %d of %d links have columns (%.1f GB resident)" % (
+                        int((pipe._link_pos >= 0).sum()), len(pipe._link_pos), 8e-9 * pipe.W.rows * pipe.W.ld)
+                    if getattr(pipe, "_link_pos", None) is not None else "dense"),
+                "active_row_blocks": row_blocks,
                 "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
                 "null_pivots": ("on: columns null to tol_qr / 64 skip their column steps (figh_tsqr_null_pivot_tol)"
                                 if pipe.null_pivots else "off"),
                 "pivots": {"dependent_max": float(np.max(np.delete(out["absdiagR"], out["idx_base"]), initial=0.0)),
                            "base_min": float(np.min(np.asarray(out["absdiagR"])[out["idx_base"]])), "tol_qr": pipe.tol_qr},
                 "fused": ("K1 + level-0 TSQR in one launch (figh_regressor_tsqr_fused), %d of the %d timed and warm-up passes"
-                          % (pipe.fused_passes, args.steps + args.warmup + 2)) if pipe.fused_passes else
+                          % (pipe.fused_passes, args.steps + args.warmup + 7) +
+                          "; first passes (kept set from a 4096-sample prefix): %d of 5 fused" % first_fused) if pipe.fused_passes else
                          "no (two launches: W written by K1, read back by the TSQR)",
             },
             "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,

@@ -482,6 +482,24 @@ int figh_model_destroy(figh_model_t model) {
     return FIGH_OK;
 }
 
+int figh_model_set_active_rows(figh_model_t model, const int32_t *h_rows, int n) {
+    FIGH_REQUIRE(model, "model is NULL");
+    unsigned long long mask = ~0ull;
+    if (h_rows && n > 0) {
+        mask = 0ull;
+        for (int k = 0; k < n; ++k) {
+            FIGH_REQUIRE(h_rows[k] >= 0 && h_rows[k] < model->host.nv && h_rows[k] < 64, "active row block out of range");
+            mask |= 1ull << h_rows[k];
+        }
+    }
+    if (mask != model->active_rows) {
+        if (g_ready) (void)hipStreamSynchronize(g_stream);
+        forget_tapes(model);  // (the tapes carry the per-row store decision)
+        model->active_rows = mask;
+    }
+    return FIGH_OK;
+}
+
 int figh_regressor_shape(figh_model_t model, int mode, int flags, int *rows_per_sample, int *ncols) {
     FIGH_REQUIRE(model, "model is NULL");
     FIGH_REQUIRE(mode == FIGH_MODE_JOINT_TORQUE || mode == FIGH_MODE_EXT_WRENCH, "bad mode");

@@ -314,40 +314,47 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
                 } else
 #endif
                 if constexpr (FAST) {
-                    // Three rows (126 chunks of 16 B) per two passes of the wave: pass A takes slots 0..63 of the three rows,
-                    // pass B slots 64..127 -- slots 126, 127 are the first two chunks of the NEXT row (written again, with
-                    // the same bytes, by the next group's pass A).  A slot's place in the padded tile is then one per-lane
-                    // constant per pass + a compile-time offset per row group: two address registers for the whole
-                    // stream-out and no branches, where chunk id -> (id + id / CH) needs one register per chunk (42 the
-                    // producer does not have) or 5 VALU operations per chunk.  Every pass is one contiguous 1 KB run in W.
-                    // Row 63 is left over: lanes 0..41.
-                    static_assert(CH <= 64 && 3 * CH <= 128 && 3 * CH > 64 && 128 - 3 * CH <= CH, "three rows per two passes");
+                    // R rows per two passes of the wave, R = 128 / CH (UR10: three rows = 126 chunks of 16 B; seven links: two rows
+                    // = 98): pass A takes slots 0..63 of the R rows, pass B slots 64..127 -- the slots behind R CH are the first
+                    // chunks of the NEXT row (written again, with the same bytes, by the next group's pass A; masked in the last
+                    // group when no row is left over).  A slot's place in the padded tile is then one per-lane constant per pass
+                    // + a compile-time offset per row group: two address registers for the whole stream-out and no branches,
+                    // where chunk id -> (id + id / CH) needs one register per chunk (42 the producer does not have) or 5 VALU
+                    // operations per chunk.  Every pass is one contiguous 1 KB run in W.  64 % R rows are left over: lanes < CH.
+                    constexpr int RG = 128 / CH;           // rows per group
+                    constexpr int NG = 64 / RG;            // groups
+                    constexpr int LEFT = 64 - NG * RG;     // rows behind the last group
+                    static_assert(CH <= 64 && RG * CH > 64 && 128 - RG * CH <= CH && LEFT <= 1, "R rows per two passes");
                     constexpr int ROWB = LDT * 8;
                     const unsigned sa = lane, sb = lane + 64;
-                    const unsigned ra = sa >= CH ? 1 : 0, rb = sb >= 3 * CH ? 3 : (sb >= 2 * CH ? 2 : 1);
+                    const unsigned ra = sa / CH, rb = sb / CH;
                     const unsigned la = ra * ROWB + 16u * (sa - ra * CH);
                     const unsigned lb = rb * ROWB + 16u * (sb - rb * CH);
                     char *gbase = reinterpret_cast<char *>(dstW) + 16 * lane;
-                    constexpr int GRP = 3 * CH * 16;  // bytes of three rows in W
-                    constexpr int NG = 21, BATCH = 3;  // 7 batches of 3 row groups: 6 reads in flight, then 6 stores
-                    static_assert(NG % BATCH == 0 && 3 * NG == 63, "63 rows in groups of three");
+                    constexpr int GRP = RG * CH * 16;  // bytes of a row group in W
+                    constexpr int BATCH = NG % 3 == 0 ? 3 : 4;  // 2 BATCH reads in flight, then 2 BATCH stores
+                    static_assert(NG % BATCH == 0, "row groups per batch");
 #pragma unroll
                     for (int g0 = 0; g0 < NG; g0 += BATCH) {
                         f64x2 va[BATCH], vb[BATCH];
 #pragma unroll
                         for (int u = 0; u < BATCH; ++u) {
-                            va[u] = *reinterpret_cast<const f64x2 *>(tbase + la + (g0 + u) * 3 * ROWB);
-                            vb[u] = *reinterpret_cast<const f64x2 *>(tbase + lb + (g0 + u) * 3 * ROWB);
+                            va[u] = *reinterpret_cast<const f64x2 *>(tbase + la + (g0 + u) * RG * ROWB);
+                            vb[u] = *reinterpret_cast<const f64x2 *>(tbase + lb + (g0 + u) * RG * ROWB);
                         }
 #pragma unroll
                         for (int u = 0; u < BATCH; ++u) {
                             *reinterpret_cast<f64x2 *>(gbase + (g0 + u) * GRP) = va[u];
-                            *reinterpret_cast<f64x2 *>(gbase + (g0 + u) * GRP + 1024) = vb[u];
+                            // (the last group has no next row to run into unless one is left over)
+                            if (LEFT > 0 || g0 + u + 1 < NG || sb < (unsigned)(RG * CH))
+                                *reinterpret_cast<f64x2 *>(gbase + (g0 + u) * GRP + 1024) = vb[u];
                         }
                     }
-                    if (lane < CH) {
-                        const f64x2 vc = *reinterpret_cast<const f64x2 *>(tbase + 63 * ROWB + 16 * lane);
-                        *reinterpret_cast<f64x2 *>(gbase + NG * GRP) = vc;
+                    if constexpr (LEFT > 0) {
+                        if (lane < CH) {
+                            const f64x2 vc = *reinterpret_cast<const f64x2 *>(tbase + 63 * ROWB + 16 * lane);
+                            *reinterpret_cast<f64x2 *>(gbase + NG * GRP) = vc;
+                        }
                     }
                 } else {
                     constexpr unsigned MAGIC = ((1u << 20) + CH - 1) / CH;
@@ -684,10 +691,13 @@ extern "C" int figh_regressor_tsqr_fused(figh_model_t model, int flags, int64_t 
     case NJ:                                                                                                      \
         rc = launch_fused<NJ>(model, f, (long)N, d_q, d_v, d_a, d_W, d_tau, d_kept, n, d_colsq, &Rws, &count);    \
         break;
+        FIGH_FUSED_CASE(5)
         FIGH_FUSED_CASE(6)
+        FIGH_FUSED_CASE(7)
 #undef FIGH_FUSED_CASE
         default:
-            set_error("fused regressor + TSQR: built for 6-joint chains");
+            // (eight links: two 58 KB tile buffers leave 17 KB of the 160 KB of LDS, less than three consumer triangles)
+            set_error("fused regressor + TSQR: serial chains of 5 to 7 joints (LDS: two tile buffers + three consumer triangles)");
             return FIGH_ERR_UNSUPPORTED;
     }
     if (rc) return rc;

@@ -36,6 +36,9 @@ struct figh_model_s {
     figh::DevModel *dev = nullptr;
     bool is_chain = false;  // fixed-base serial chain of revolute joints: eligible for the chain kernel
     int max_depth = 0;
+    // figh_model_set_active_rows: bit j set <=> row block j (the rows of dof j, joint-torque mode of a tree) is stored by
+    // figh_regressor_build_padded; the norms of diag(W^T W) always cover every row block
+    unsigned long long active_rows = ~0ull;
 };
 
 namespace figh {
@@ -92,6 +95,9 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
                           const double *v, const double *a, double *W, long ldw, int ncols, int link_stride,
                           double *d_colsq, int *colsq_done);
 void forget_tapes(const figh_model_s *m);
+// link -> segment position of the link-compact layout (FIGH_FLAG_LINK_COMPACT), -1 = no segment; returns the number of links
+// with a segment or -1 when the layout does not apply
+int tree_link_positions(const figh_model_s *m, int mode, int flags, int ft_mask, int *pos);
 
 // figh_tsqr_wide.hip: the blocked (compact-WY, MFMA) level for nc > 80 columns
 long tsqr_wide_workgroups(int nc, int cus);

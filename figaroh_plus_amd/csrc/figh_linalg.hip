@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void select_columns_kernel(const double *__res
                                                              const double tol_e, const int link_stride, const int nblocks,
                                                              const long rows, const long rows_per_block,
                                                              const long ntiles, int *__restrict__ sel,
-                                                             int *__restrict__ tile_first) {
+                                                             int *__restrict__ tile_first,
+                                                             const int *__restrict__ link_pos = nullptr) {
     __shared__ int kept[1024];
     __shared__ int first[kMaxJoints];
     const int tid = threadIdx.x;
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(256) void select_columns_kernel(const double *__res
     for (int c = tid; c < ncols; c += 256) {
         int pos = 0;
         for (int e = 0; e < c; ++e) pos += kept[e];
-        if (kept[c]) sel[2 + pos] = (c / 14) * link_stride + c % 14;
+        // (link_pos: the link-compact layout of figh_regressor_build_padded + FIGH_FLAG_LINK_COMPACT -- a kept column's link
+        // always has a segment there: columns of links without one have norm exactly 0)
+        if (kept[c]) sel[2 + pos] = (link_pos ? max(link_pos[c / 14], 0) : c / 14) * link_stride + c % 14;
         if (c >= total) sel[2 + c] = 0;
         sel[2 + ncols + c] = kept[c];
     }
@@ -828,7 +831,7 @@ int figh_select_columns(const double *d_colsq, int ncols, double tol_e, int link
     if (int rc = ensure_device()) return rc;
     ProfileScope scope("select_columns");
     hipLaunchKernelGGL(select_columns_kernel, dim3(1), dim3(256), 0, stream(), d_colsq, ncols, tol_e, link_stride, 0, 0L,
-                       1L, 0L, d_sel, (int *)nullptr);
+                       1L, 0L, d_sel, (int *)nullptr, (const int *)nullptr);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }
@@ -874,9 +877,18 @@ int figh::tsqr_reduce_stack(const double *d_Rs, long count, int nc, int n_free, 
 
 extern "C" {
 
+static int tsqr_selected_impl(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                              int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
+                              double *d_R_out, const int32_t *d_link_pos);
 int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                        int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
                        double *d_R_out) {
+    return tsqr_selected_impl(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, nblocks, n_expected, d_tau, tol_qr, d_sel,
+                              d_R_out, nullptr);
+}
+static int tsqr_selected_impl(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
+                              int link_stride, int nblocks, int n_expected, const double *d_tau, double tol_qr, int32_t *d_sel,
+                              double *d_R_out, const int32_t *d_link_pos) {
     FIGH_REQUIRE(d_W && d_colsq && d_sel, "NULL device pointer");
     FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
     FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
@@ -897,7 +909,7 @@ int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const doubl
         const long grid = hinted ? (ntiles + 255) / 256 : 1;
         hipLaunchKernelGGL(select_columns_kernel, dim3((unsigned)grid), dim3(256), 0, stream(), d_colsq, ncols, tol_e,
                            link_stride, hinted ? nblocks : 0, (long)rows, hinted ? (long)(rows / nblocks) : 1L,
-                           hinted ? ntiles : 0L, d_sel, d_tile);
+                           hinted ? ntiles : 0L, d_sel, d_tile, (const int *)d_link_pos);
         FIGH_HIP(hipGetLastError());
     }
     if (n_expected <= 0) return FIGH_OK;  // selection only (the caller does not know the count yet)
@@ -918,13 +930,14 @@ int figh_tsqr_selected(const double *d_W, int64_t rows, int64_t ldw, const doubl
 // W, at 0.5 (1 + (nf / n)^2) of the flops (TALOS, human: 58 %).
 int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nf_expected, const double *d_tau, double tol_qr,
-                              int32_t *d_sel, double *d_R_out) {
+                              int32_t *d_sel, double *d_R_out, const int32_t *d_link_pos) {
     const int nc = n_expected + (d_tau ? 1 : 0);
+    FIGH_REQUIRE(!d_link_pos || link_stride == 16, "a link map goes with the link-padded layout");
     // no split: unknown counts, the register-tile kernel's column range (no chained form), nothing to gain, odd shapes
     if (n_expected <= 0 || nf_expected <= 0 || nf_expected >= n_expected || nc <= 80 || rows % 6 != 0 ||
         rows / 2 < 16L * nc)
-        return figh_tsqr_selected(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, 0, n_expected, d_tau, tol_qr, d_sel,
-                                  d_R_out);
+        return tsqr_selected_impl(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, 0, n_expected, d_tau, tol_qr, d_sel,
+                                  d_R_out, d_link_pos);
     FIGH_REQUIRE(d_W && d_colsq && d_sel && d_R_out, "NULL device pointer");
     FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
     FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
@@ -933,7 +946,7 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
     {
         ProfileScope scope("select_columns");
         hipLaunchKernelGGL(select_columns_kernel, dim3(1), dim3(256), 0, stream(), d_colsq, ncols, tol_e, link_stride, 0,
-                           (long)rows, 1L, 0L, d_sel, (int *)nullptr);
+                           (long)rows, 1L, 0L, d_sel, (int *)nullptr, (const int *)d_link_pos);
         FIGH_HIP(hipGetLastError());
     }
     const int n = n_expected, nf = nf_expected, ncf = nf + (d_tau ? 1 : 0);
@@ -996,15 +1009,16 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     {
         ProfileScope scope("select_columns");
         hipLaunchKernelGGL(select_columns_kernel, dim3(1), dim3(256), 0, stream(), d_colsq, ncols, tol_e, link_stride, 0,
-                           (long)rows, 1L, 0L, d_sel, (int *)nullptr);
+                           (long)rows, 1L, 0L, d_sel, (int *)nullptr, (const int *)nullptr);
         FIGH_HIP(hipGetLastError());
     }
     const int n = n_expected, nc = n + (d_tau ? 1 : 0);
     const int64_t rows_b = rows / nblocks;
     int nmax = 1;
     for (int j = 0; j < nblocks; ++j) {
-        FIGH_REQUIRE(h_counts[j] >= 0 && h_counts[j] <= n, "block column count out of range");
-        nmax = std::max(nmax, h_counts[j] + (d_tau ? 1 : 0));
+        // (-1: an INACTIVE row block -- neither its rows of W nor of tau take part; figh_model_set_active_rows)
+        FIGH_REQUIRE(h_counts[j] >= -1 && h_counts[j] <= n, "block column count out of range");
+        if (h_counts[j] >= 0) nmax = std::max(nmax, h_counts[j] + (d_tau ? 1 : 0));
     }
     const size_t tri = sizeof(double) * (size_t)nc * nc;
     // The per-row-block triangles, embedded into the kept column set, are stacked COMPACTLY: block j contributes its
@@ -1014,7 +1028,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     // + figh_tsqr over the rows with per-row weights), else in a library workspace.
     long rows_total = 0;
     for (int j = 0; j < nblocks; ++j)
-        if (h_counts[j] > 0 || d_tau) rows_total += h_counts[j] + (d_tau ? 1 : 0);
+        if (h_counts[j] > 0 || (d_tau && h_counts[j] == 0)) rows_total += h_counts[j] + (d_tau ? 1 : 0);
     double *stack = d_block_tri ? d_block_tri
                                 : static_cast<double *>(workspace(sizeof(double) * (size_t)(rows_total + nc + 1) * nc, 26));
     const int64_t cap_b = std::max(figh_tsqr_level0_capacity(nmax), figh_tsqr_level0_capacity(std::min(nmax, 80)));
@@ -1057,7 +1071,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         const double *Wj = h_block_off ? d_W + h_block_off[j] : d_W + (int64_t)j * rows_b * ldw;
         const int64_t ldj = h_block_ld ? h_block_ld[j] : ldw;
         const double *tj = d_tau ? d_tau + (int64_t)j * rows_b : nullptr;
-        if (nj == 0 && !d_tau) continue;  // (nothing of this block is kept)
+        if (nj < 0 || (nj == 0 && !d_tau)) continue;  // (an inactive row block / nothing of this block is kept)
         if (grouped && nj >= 1 && ncj <= 64) {
             Tsqr2Job J{};
             J.W = Wj;

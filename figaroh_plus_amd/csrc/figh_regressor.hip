@@ -525,6 +525,20 @@ extern "C" int figh_regressor_build(figh_model_t model, int mode, int flags, int
     return FIGH_OK;
 }
 
+extern "C" int figh_regressor_link_layout(figh_model_t model, int mode, int flags, int ft_mask, int32_t *h_link_pos,
+                                          int *nlive) {
+    FIGH_REQUIRE(model && h_link_pos && nlive, "NULL pointer");
+    int pos[kMaxJoints];
+    const int live = tree_link_positions(model, mode, flags, ft_mask, pos);
+    if (live < 0) {
+        set_error("link-compact W: external-wrench regressor of a model with a free-flyer root only");
+        return FIGH_ERR_UNSUPPORTED;
+    }
+    for (int l = 0; l < model->host.nlinks; ++l) h_link_pos[l] = pos[l];
+    *nlive = live;
+    return FIGH_OK;
+}
+
 // Link-padded form of figh_regressor_build for W that stays on the device (see figh.h): 16 columns per link.
 extern "C" int figh_regressor_build_padded(figh_model_t model, int mode, int flags, int ft_mask, int64_t N,
                                            const double *d_q, const double *d_v, const double *d_a, double *d_W,
@@ -547,7 +561,8 @@ extern "C" int figh_regressor_build_padded(figh_model_t model, int mode, int fla
         return FIGH_OK;
     }
     int done = 0;
-    return launch_regressor_tree(model, mode, flags & (7 | FIGH_FLAG_BLOCKED_INPUTS | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS),
+    return launch_regressor_tree(model, mode, flags & (7 | FIGH_FLAG_BLOCKED_INPUTS | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS |
+                                                       FIGH_FLAG_LINK_COMPACT),
                                  ft_mask, N,
                                  d_q, d_v, d_a, d_W, ldw,
                                  ncols, 16, d_colsq, &done);

@@ -59,7 +59,7 @@ enum : int32_t { OP_RESET = 0, OP_STEP = 1, OP_EMIT = 2, OP_ZERO = 3, OP_TX40 = 
 // bits 8.. = FETCH slot
 enum : int32_t { STEP_JSTART = 1 };
 // EMIT flags (field c)
-enum : int32_t { EMIT_INERT = 1, EMIT_EXTRA = 2, EMIT_OWN = 4, EMIT_FLUSH = 8 };
+enum : int32_t { EMIT_INERT = 1, EMIT_EXTRA = 2, EMIT_OWN = 4, EMIT_FLUSH = 8, EMIT_NOSTORE = 16 };
 constexpr int kFetch = 5;  // joints per FETCH group (the five payload fields of an op)
 
 struct TapeOp {
@@ -83,7 +83,8 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
                                            double *__restrict__ colacc, const int lane, const int nvalid,
                                            double *__restrict__ W, const long ldw, const unsigned ldw8, const long rowbase,
                                            const int col0, double &acc0, double &acc1, const bool fold,
-                                           const bool skip_lo = false, const int col0_acc = -1) {
+                                           const bool skip_lo = false, const int col0_acc = -1,
+                                           const bool nostore = false) {
     constexpr int CP = LS / 2, RPI = 64 / CP;  // 16-byte chunks per row, rows per store instruction
     constexpr int LSP = FIGH_TREE_LSP;         // LDS row stride of the tile (see regressor_tape_kernel)
     const int rg = lane / CP, ch = lane - rg * CP;
@@ -103,7 +104,7 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
                     acc0 = fma(x.x, x.x, acc0);
                     acc1 = fma(x.y, x.y, acc1);
                 }
-                if (STORE && !(skip_lo && ch < CP / 2)) {
+                if (STORE && !nostore && !(skip_lo && ch < CP / 2)) {
                     u32x4 d;
                     d[0] = (unsigned)__double2loint(x.x);
                     d[1] = (unsigned)__double2hiint(x.x);
@@ -379,7 +380,9 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
             if (op == OP_EMIT) {
                 // ---- the segment of link oa: EXTFF in all six row blocks (od = components with inertial entries),
                 // otherwise in row block ob
-                const int b = oa, col0 = LS * (b - 1);
+                // (external wrench with FIGH_FLAG_LINK_COMPACT: the link's segment sits at its position among the links that
+                // have one, oe - 1; otherwise at its place in the link-padded row)
+                const int b = oa, col0 = (EXTFF && oe > 0) ? oe - 1 : LS * (b - 1);
                 double ex[4] = {0.0, 0.0, 0.0, 0.0};
                 if (oc & EMIT_EXTRA) {  // regressor.py:55-70 (own row) / :142-169 (all six rows): Ia fv fs off of link b
                     // joint-torque mode writes them on the link's own row, right after its STEP: dof b - 1 is that joint
@@ -444,16 +447,18 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                             // segment's column in it | ld << 16, oe = the prefix sum
                             const long ldc = od >> 16;
                             flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W + (long)N * oe, ldc,
-                                                         8u * (unsigned)ldc, i0, (od & 0xffff) - 1, cs0, cs1, fold, false, col0);
+                                                         8u * (unsigned)ldc, i0, (od & 0xffff) - 1, cs0, cs1, fold, false, col0,
+                                                         (oc & EMIT_NOSTORE) != 0);
                         } else {
 #ifdef FIGH_ABLATION
                             flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0, cs0, cs1, fold,
                                                          EXTFF && g_tree_half && c < 3);
 #else
-                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0, cs0, cs1, fold);
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0, cs0, cs1, fold,
+                                                         false, -1, !EXTFF && (oc & EMIT_NOSTORE) != 0);
 #endif
                         }
-                    } else {  // odd column count / unaligned W: plain 8-byte stores, no fused norms
+                    } else if (!(oc & EMIT_NOSTORE)) {  // odd column count / unaligned W: plain 8-byte stores, no fused norms
                         for (int id = lane; id < nvalid * 14; id += 64) {
                             const int row = id / 14, col = id - 14 * row;
                             W[(rowbase + row) * ldw + col0 + col] = tile[row * LSP + col];
@@ -510,12 +515,17 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
 // partial[b][LS l + s] -> out[14 l + s]: one workgroup per reference column, strided partial sums + LDS tree (fixed
 // order: deterministic)
 __global__ __launch_bounds__(256) void reduce_tree_partials_kernel(const double *__restrict__ part, int nblocks,
-                                                                   int ncols_int, int ls, double *__restrict__ out) {
+                                                                   int ncols_int, int ls, const int *__restrict__ link_pos,
+                                                                   double *__restrict__ out) {
     __shared__ double sm[256];
     const int c = blockIdx.x;
-    const int ci = (c / 14) * ls + c % 14;
+    // link_pos (FIGH_FLAG_LINK_COMPACT): position of a link's segment in W, -1 for a link without one (all its entries are
+    // structural zeros: norm exactly 0)
+    const int lp = link_pos ? link_pos[c / 14] : c / 14;
+    const int ci = lp * ls + c % 14;
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long)b * ncols_int + ci];
+    if (lp >= 0)
+        for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long)b * ncols_int + ci];
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
@@ -587,13 +597,15 @@ std::vector<TapeOp> with_fetches(const DevModel &h, const std::vector<TapeOp> &i
 }
 
 // external wrench, free-flyer root: one walk over the tree, six row segments per link (ls = columns per link in W)
-std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, int ls) {
+std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, int ls, const int *link_pos) {
     TapeBuilder T(h);
     const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
     int prev = 0, zero_from = -1;
     auto flush_zero = [&](int upto_link) {  // links zero_from .. upto_link-1 (1-based joints) are all-zero segments
         if (zero_from < 0) return;
-        for (int c = 0; c < 6; ++c) T.zero(c, ls * (zero_from - 1), ls * (upto_link - zero_from));
+        // (link-compact W: such links have no columns at all)
+        if (!link_pos)
+            for (int c = 0; c < 6; ++c) T.zero(c, ls * (zero_from - 1), ls * (upto_link - zero_from));
         zero_from = -1;
     };
     T.push(OP_RESET);
@@ -607,7 +619,8 @@ std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, 
         const int inert = h.body_mask[b] ? (ft_mask & 63) : 0;
         if (inert || extras) {
             flush_zero(b);
-            T.push(OP_EMIT, b, 0, (inert ? EMIT_INERT : 0) | (extras ? EMIT_EXTRA : 0), inert);
+            T.push(OP_EMIT, b, 0, (inert ? EMIT_INERT : 0) | (extras ? EMIT_EXTRA : 0), inert,
+                   link_pos ? ls * link_pos[b - 1] + 1 : 0);
         } else if (zero_from < 0) {
             zero_from = b;
         }
@@ -619,7 +632,8 @@ std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, 
 // One row block per dof.  Joint-torque mode: every joint is single-dof and has its row.  External wrench on a fixed
 // base: rows = the first six joints; inertial entries only for links with mass and components in ft_mask, Ia / fv / fs /
 // off on all six rows of every link (regressor.py:142-169).
-std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int ft_mask, int ls) {
+std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int ft_mask, int ls,
+                                    unsigned long long active_rows) {
     TapeBuilder T(h);
     const bool ext = mode == FIGH_MODE_EXT_WRENCH;
     const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
@@ -634,13 +648,16 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
         const int s0 = j > 0 ? j : nl + 1, s1 = j > 0 ? T.subtree_end(j) : nl + 1;  // links s0 .. s1-1 = subtree
         int prev = -1, zero_from = -1;
         const bool compact = (flags & FIGH_FLAG_COMPACT_BLOCKS) != 0;
+        // figh_model_set_active_rows: a row block that is not stored is still walked (its entries count in diag(W^T W))
+        const bool stored = ext || ((active_rows >> row) & 1ull);
         auto flush_zero = [&](int upto_link) {
             if (zero_from < 0) return;
-            if (!(flags & (FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS)))
+            if (stored && !(flags & (FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS)))
                 T.zero(row, ls * (zero_from - 1), ls * (upto_link - zero_from));
             zero_from = -1;
         };
-        const int ld_row = ls * (s1 - s0);  // block-compact: the row block's own leading dimension (its subtree's links)
+        // block-compact: the row block's own leading dimension (its subtree's links); 0 for a block that is not stored
+        const int ld_row = stored ? ls * (s1 - s0) : 0;
         for (int b = 1; b <= nl; ++b) {
             const bool in_sub = b >= s0 && b < s1;
             const bool inert = row_inert && in_sub && (!ext || h.body_mask[b]);
@@ -656,8 +673,9 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
             if (inert || extra) {
                 flush_zero(b);
                 T.push(OP_EMIT, b, row,
-                       (inert ? EMIT_INERT : 0) | (extra ? EMIT_EXTRA : 0) | ((!ext && b == j && row_inert) ? EMIT_OWN : 0),
-                       compact ? ((ls * (b - s0) + 1) | (ld_row << 16)) : 0, compact ? compact_prefix : 0);
+                       (inert ? EMIT_INERT : 0) | (extra ? EMIT_EXTRA : 0) | ((!ext && b == j && row_inert) ? EMIT_OWN : 0) |
+                           (stored ? 0 : EMIT_NOSTORE),
+                       (compact && stored) ? ((ls * (b - s0) + 1) | (ld_row << 16)) : 0, compact ? compact_prefix : 0);
             } else if (zero_from < 0) {
                 zero_from = b;
             }
@@ -673,10 +691,28 @@ struct DeviceTape {
     TapeOp *dev = nullptr;
     int n = 0;
     bool extff = false;
+    int *link_pos = nullptr;  // FIGH_FLAG_LINK_COMPACT: device copy of the link -> segment position map (nlinks entries)
+    int nlive = 0;
 };
 std::map<std::vector<long>, DeviceTape> g_tapes;  // (model handle, mode, flags, ft_mask, ls) -> tape
 
 }  // namespace
+
+// FIGH_FLAG_LINK_COMPACT (external wrench on a free-flyer root): position of every link's 16-column segment among the links
+// that have one -- a link with mass (and a wrench component selected) or, with friction / inertia / offset flags, every link;
+// -1 for the others, whose entries are structural zeros in all six row blocks (regressor.py:36-39: massless bodies are
+// skipped).  Returns the number of links with a segment, or -1 when the layout does not apply to (model, mode).
+int tree_link_positions(const figh_model_s *m, int mode, int flags, int ft_mask, int *pos) {
+    const DevModel &h = m->host;
+    if (!(mode == FIGH_MODE_EXT_WRENCH && h.njoints > 1 && h.jtype[1] == FIGH_JT_FREEFLYER) || (flags & FIGH_FLAG_TX40)) return -1;
+    const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
+    int live = 0;
+    for (int b = 1; b < h.njoints; ++b) {
+        const bool inert = h.body_mask[b] && (ft_mask & 63);
+        pos[b - 1] = (inert || extras) ? live++ : -1;
+    }
+    return live;
+}
 
 // internal: rows of W for a tree model.  ls = columns per link in W: 14 (the reference's layout, ncols = 14 nlinks [+ 3])
 // or 16 (link-padded: columns 14, 15 of every link are zero, every row segment is one 128-byte line; needs ldw % 16 == 0
@@ -691,7 +727,13 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     FIGH_REQUIRE(store || d_colsq, "nothing to compute");
     FIGH_REQUIRE(ls == 14 || ls == 16, "link stride must be 14 or 16");
     FIGH_REQUIRE(ls == 14 || !(flags & FIGH_FLAG_TX40), "the link-padded layout has no TX40 coupling columns");
-    const int ncols_int = ls * h.nlinks + ((flags & FIGH_FLAG_TX40) ? 3 : 0);
+    int link_pos[kMaxJoints];
+    int nlive = -1;
+    if (flags & FIGH_FLAG_LINK_COMPACT) {
+        nlive = tree_link_positions(m, mode, flags, ft_mask, link_pos);
+        FIGH_REQUIRE(nlive >= 0 && ls == 16, "link-compact W: external-wrench regressor of a free-flyer model, link-padded columns");
+    }
+    const int ncols_int = nlive >= 0 ? ls * (nlive > 0 ? nlive : 1) : ls * h.nlinks + ((flags & FIGH_FLAG_TX40) ? 3 : 0);
     if (!store) ldw = ncols_int;
     FIGH_REQUIRE(ldw >= ncols_int, "ldw smaller than the number of columns");
     FIGH_REQUIRE(ldw < (1L << 22), "figh_regressor_build: leading dimension must be below 2^22 elements");
@@ -707,11 +749,13 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
         FIGH_REQUIRE(16L * h.nlinks < (1L << 15), "block-compact W: too many links");
     }
     const std::vector<long> key = {(long)reinterpret_cast<uintptr_t>(m), mode,
-                                   flags & (7 | FIGH_FLAG_TX40 | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS), ft_mask,
+                                   flags & (7 | FIGH_FLAG_TX40 | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS |
+                                            FIGH_FLAG_LINK_COMPACT), ft_mask,
                                    ls};
     auto it = g_tapes.find(key);
     if (it == g_tapes.end()) {
-        std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls) : build_tape_rows(h, mode, flags, ft_mask, ls);
+        std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls, nlive >= 0 ? link_pos : nullptr)
+                                        : build_tape_rows(h, mode, flags, ft_mask, ls, m->active_rows);
 #ifdef FIGH_ABLATION
         {
             const int hot = getenv("FIGH_TREE_HOTIN") != nullptr;
@@ -744,6 +788,14 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
             return FIGH_ERR_ALLOC;
         }
         FIGH_HIP(hipMemcpy(dt.dev, ops.data(), sizeof(TapeOp) * ops.size(), hipMemcpyHostToDevice));
+        if (nlive >= 0) {
+            dt.nlive = nlive;
+            if (hipMalloc(&dt.link_pos, sizeof(int) * kMaxJoints) != hipSuccess) {
+                set_error("hipMalloc(link map) failed");
+                return FIGH_ERR_ALLOC;
+            }
+            FIGH_HIP(hipMemcpy(dt.link_pos, link_pos, sizeof(int) * h.nlinks, hipMemcpyHostToDevice));
+        }
         it = g_tapes.emplace(key, dt).first;
     }
     const DeviceTape &tp = it->second;
@@ -792,7 +844,7 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     if (fuse) {
         const int nref = 14 * h.nlinks;  // (TX40 tail: never fused, odd column count)
         hipLaunchKernelGGL(reduce_tree_partials_kernel, dim3(nref), dim3(256), 0, stream(), part, (int)grid, ncols_int, ls,
-                           d_colsq);
+                           (const int *)tp.link_pos, d_colsq);
         FIGH_HIP(hipGetLastError());
     }
     return FIGH_OK;
@@ -802,6 +854,7 @@ void forget_tapes(const figh_model_s *m) {  // figh_model_destroy
     for (auto it = g_tapes.begin(); it != g_tapes.end();) {
         if (it->first[0] == (long)reinterpret_cast<uintptr_t>(m)) {
             (void)hipFree(it->second.dev);
+            if (it->second.link_pos) (void)hipFree(it->second.link_pos);
             it = g_tapes.erase(it);
         } else {
             ++it;

@@ -26,11 +26,15 @@ __global__ __launch_bounds__(256) void vec_add_kernel(double *__restrict__ acc, 
 }
 
 // reference column 14 l + s -> link-padded column 16 l + s (a NULL list = all columns)
-__global__ __launch_bounds__(256) void pad_columns_kernel(const int32_t *__restrict__ in, int n, int32_t *__restrict__ out) {
+// (link_pos: the link-compact layout, FIGH_FLAG_LINK_COMPACT -- a link without a segment only has eliminated columns, which
+// no caller lists; should one be listed all the same it reads segment 0: values of another column, never out of range)
+__global__ __launch_bounds__(256) void pad_columns_kernel(const int32_t *__restrict__ in, int n, int32_t *__restrict__ out,
+                                                          const int *__restrict__ link_pos) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         const int c = in ? in[i] : i;
-        out[i] = (c / 14) * 16 + c % 14;
+        const int l = link_pos ? max(link_pos[c / 14], 0) : c / 14;
+        out[i] = l * 16 + c % 14;
     }
 }
 
@@ -127,13 +131,27 @@ static int regressor_tsqr_impl(figh_model_t model, int mode, int flags, int ft_m
     // the chunk's W is a private workspace: tree models get the link-padded layout (16 columns per link, every row
     // segment one 128-byte line) and the caller's column list is translated to it
     const bool padded = !(model->is_chain && mode == FIGH_MODE_JOINT_TORQUE) && !(flags & FIGH_FLAG_TX40);
-    const int64_t ldc = padded ? 16 * (int64_t)model->host.nlinks : ncols;
+    // external wrench on a free-flyer root: links without entries (massless bodies) get no columns in the chunk's W
+    // (FIGH_FLAG_LINK_COMPACT; the caller's column list can only name them if it keeps columns that are identically zero)
+    int link_pos[kMaxJoints];
+    int *d_link_pos = nullptr;
+    int nlive = padded ? tree_link_positions(model, mode, flags & 7, ft_mask, link_pos) : -1;
+    if (nlive <= 0 || nlive >= model->host.nlinks) nlive = -1;
+    if (nlive > 0) {
+        d_link_pos = static_cast<int *>(workspace(sizeof(int) * kMaxJoints, 37));
+        if (!d_link_pos) return FIGH_ERR_ALLOC;
+        FIGH_HIP(hipMemcpyAsync(d_link_pos, link_pos, sizeof(int) * model->host.nlinks, hipMemcpyHostToDevice, stream()));
+        FIGH_HIP(hipStreamSynchronize(stream()));  // (link_pos lives on this stack frame)
+        flags |= FIGH_FLAG_LINK_COMPACT;
+    }
+    const int64_t ldc = padded ? 16 * (int64_t)(nlive > 0 ? nlive : model->host.nlinks) : ncols;
     double *Wc = static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs * ldc, 8));
     int32_t *d_cols = const_cast<int32_t *>(d_col_idx);
     if (padded) {
         d_cols = static_cast<int32_t *>(workspace(sizeof(int32_t) * (size_t)n, 9));
         if (!d_cols) return FIGH_ERR_ALLOC;
-        hipLaunchKernelGGL(pad_columns_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), d_col_idx, n, d_cols);
+        hipLaunchKernelGGL(pad_columns_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), d_col_idx, n, d_cols,
+                           (const int *)d_link_pos);
         FIGH_HIP(hipGetLastError());
     }
     double *tc = d_tau ? static_cast<double *>(workspace(sizeof(double) * (size_t)rps * cs, 10)) : nullptr;
@@ -306,7 +324,8 @@ extern "C" int figh_regressor_tsqr_batch(figh_model_t model, int mode, int flags
     if (padded) {
         d_cols = static_cast<int32_t *>(workspace(sizeof(int32_t) * (size_t)n, 9));
         if (!d_cols) return FIGH_ERR_ALLOC;
-        hipLaunchKernelGGL(pad_columns_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), d_col_idx, n, d_cols);
+        hipLaunchKernelGGL(pad_columns_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), d_col_idx, n, d_cols,
+                           (const int *)nullptr);
         FIGH_HIP(hipGetLastError());
     }
     if (int rc = padded ? figh_regressor_build_padded(model, mode, flags, ft_mask, N_tot, d_q, d_v, d_a, Wc, ldc, nullptr)

@@ -345,13 +345,28 @@ class _DevView:
         self.ptr = base.ptr + int(byte_offset)
 
 
-def _decimate_device(W, tau, nblocks, q, stages):
+def _decimate_device(W, tau, nblocks, q, stages, blocks=None):
     """decimate_joint_blocks for a regressor that lives in HBM: the stages run device buffer to device buffer
     (figh_filtfilt_cols), the blocks come back as GpuMatrix / device-vector views of one stacked result."""
     sos, zi, padlen = _decimate_design(q)
     d_tau = vector_to_device(tau)
     ntau = getattr(d_tau, "size", None) or len(tau)
     nj = ntau // nblocks
+    if blocks is not None:
+        # active joints: tau block i goes with the rows [blocks[i] nj, (blocks[i] + 1) nj) of W -- gathered into one stack on
+        # the device (a copy of the active blocks only), then decimated like a regressor that has just these blocks
+        if W.rows < (max(blocks) + 1) * nj:
+            raise ValueError("device-resident decimation needs W to cover row block %d" % max(blocks))
+        stack = GpuMatrix.empty(nblocks * nj, W.cols)
+        lib = _lib.load()
+        for i, b in enumerate(blocks):
+            if W.ld == W.cols:
+                _lib.check(lib.figh_memcpy_d2d(stack.buf.ptr + 8 * i * nj * W.cols, W.buf.ptr + 8 * b * nj * W.ld,
+                                               8 * nj * W.cols))
+            else:
+                _lib.place_block(W.buf.ptr + 8 * b * nj * W.ld, W.ld, nj, W.cols, 1.0,
+                                 stack.buf.ptr + 8 * i * nj * W.cols, W.cols)
+        W = stack
     if W.rows < nblocks * nj:
         raise ValueError("device-resident decimation needs W to cover the %d joint blocks of tau" % nblocks)
 
@@ -466,7 +481,7 @@ def essential_parameters(R_ols, R_wls, params_base, std_xr, ratio_essential, row
 
 
 
-def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
+def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2, blocks=None):
     """Per-joint decimation of tau and of every column of W with ``scipy.signal.decimate(zero_phase=True)``
     (examples/staubli_TX40/identification.py:186-204, examples/tiago/identification.py:142-187).
     Returns (list of W blocks, list of tau blocks).  Block i of W is ``W[i*nj:(i+1)*nj]`` with nj taken from tau, as in
@@ -475,12 +490,25 @@ def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2):
     equal-length blocks share a launch.
 
     A ``GpuMatrix`` W (``param["device_resident"]``) stays in HBM: the blocks come back as GpuMatrix views and device
-    vectors (for :func:`reject_rows`), nothing is copied to the host."""
+    vectors (for :func:`reject_rows`), nothing is copied to the host.
+
+    ``blocks`` (ACTIVE JOINTS, examples/tiago/identification.py:148-187: ``act_idxv``): W is the regressor of ALL dofs, tau
+    holds the ``nblocks = len(blocks)`` measured joints only, and block i of the result is the decimated row block
+    ``blocks[i]`` of W -- ``W[blocks[i]*nj:(blocks[i]+1)*nj]`` -- the other row blocks are never touched.  The TIAGo script
+    decimates once (``stages=1``)."""
+    if blocks is not None:
+        blocks = [int(b) for b in blocks]
+        if len(blocks) != nblocks:
+            raise ValueError("decimate_joint_blocks: %d blocks listed, nblocks = %d" % (len(blocks), nblocks))
     if isinstance(W, GpuMatrix):
-        return _decimate_device(W, tau, nblocks, q, stages)
+        return _decimate_device(W, tau, nblocks, q, stages, blocks)
     W = np.asarray(W, dtype=np.float64)
     tau = np.asarray(tau, dtype=np.float64)
     nj = tau.shape[0] // nblocks
+    if blocks is not None:
+        if W.shape[0] < (max(blocks) + 1) * nj:
+            raise ValueError("decimate_joint_blocks: W does not cover row block %d" % max(blocks))
+        W = np.concatenate([W[b * nj:(b + 1) * nj] for b in blocks])  # the active blocks only, in the listed order
     sos, zi, padlen = _decimate_design(q)
 
     def run(x2d, nb):  # nb equal blocks stacked in x2d

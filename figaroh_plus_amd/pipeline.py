@@ -81,12 +81,21 @@ def _solve_upper(R1, B):
 
 class IdentificationPipeline:
     def __init__(self, robot, param, params_std=None, coupling=False, tol_e=1e-6, tol_qr=qrd.TOL_QR, exchange=None,
-                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass", w_layout="dense", fuse=True, null_pivots=True):
+                 chunk_samples=None, placement_trials=1, structural_zeros="every-pass", w_layout="dense", fuse=True, null_pivots=True,
+                 row_blocks=None):
         """``chunk_samples``: when the stacked regressor of all N samples does not fit HBM (human model at 1e7
         samples: 269 GB) the samples are processed in chunks of this size -- pass 1 accumulates diag(W^T W), pass 2
         rebuilds each chunk's W (recomputing is far cheaper than storing), factors it and stacks the triangles,
         which ``figh_tsqr_merge`` reduces.  Results are those of the one-shot pass (R is row-order independent)."""
         self.chunk_samples = chunk_samples
+        # row_blocks (ACTIVE JOINTS, examples/tiago/identification.py:148-187, :406-424): the dof indices (``act_idxv``) whose
+        # row blocks carry measurements.  As in the script, the columns are eliminated on the norms of the FULL regressor
+        # (every row block is walked for diag(W^T W)), but only the listed blocks are stored, and only they -- with their tau
+        # -- are factored.  ``tau`` of set_samples then has len(row_blocks) * N entries, block i belonging to dof
+        # row_blocks[i] (the script's tau[:, i]); out["rows"], sigma2_joint follow the list.  Joint-torque regressors of trees
+        # of single-dof joints (the per-row-block TSQR), W resident.
+        self.row_blocks = None if row_blocks is None else [int(b) for b in row_blocks]
+        self._own_handle = None
         # fuse (serial chains, W in the reference layout): from the second pass on K1 and the level-0 TSQR run as ONE launch
         # (figh_regressor_tsqr_fused) over the kept-column list of the previous pass -- every 64-row tile of W is factored
         # while it is still in LDS, W is written but not read back.  The list is verified against the norms the pass produces;
@@ -107,8 +116,9 @@ class IdentificationPipeline:
         # Nothing else is written or read (the TSQR takes one column list per row block anyway); every stored byte is written
         # in every pass.  self.W is then that buffer (rows = nv N, `compact` = (offsets, leading dimensions)), not the
         # reference's matrix: build_regressor_basic still returns that.
-        if w_layout not in ("dense", "block-compact"):
-            raise ValueError("w_layout must be 'dense' or 'block-compact'")
+        # "link-padded": trees in the plain link-padded layout even where the link-compact one applies (tests, A/B).
+        if w_layout not in ("dense", "block-compact", "link-padded"):
+            raise ValueError("w_layout must be 'dense', 'block-compact' or 'link-padded'")
         self.w_layout = w_layout
         # placement_trials > 1: when W is allocated, that many candidate buffers are allocated side by side, the regressor
         # kernel is timed on each and the fastest one is kept (set-up cost: a few passes of K1).  The time K1 needs for the
@@ -125,6 +135,19 @@ class IdentificationPipeline:
         self.d_q = self.d_v = self.d_a = self.d_tau = None
         self.W = None
 
+    def _handle(self):
+        """The device model of this pipeline: the robot's shared handle, or -- with ``row_blocks`` -- a private one that
+        stores the active row blocks only (figh_model_set_active_rows changes what a handle writes)."""
+        if self.row_blocks is None:
+            return self.robot.device_model()
+        if self._own_handle is None:
+            m = self.robot.model
+            if sorted(set(self.row_blocks)) != sorted(self.row_blocks) or not all(0 <= b < m.nv for b in self.row_blocks):
+                raise ValueError("row_blocks must be distinct dof indices in [0, %d)" % m.nv)
+            self._own_handle = _lib.ModelHandle(m.to_flat())
+            self._own_handle.set_active_rows(self.row_blocks)
+        return self._own_handle
+
     # ------------------------------------------------------------------ inputs
     def set_samples(self, q, v, a, tau=None):
         """Upload this rank's samples (q: N x nq, v/a: N x nv) and optionally tau (rows of W,).
@@ -134,11 +157,22 @@ class IdentificationPipeline:
         from .tools.regressor import _samples_to_device, regressor_flags
         mode, _, _ = regressor_flags(self.param, self.coupling)
         rps = self.robot.model.nv if mode == _lib.MODE_JOINT_TORQUE else 6  # figh_regressor_shape
+        if self.row_blocks is not None:
+            if mode != _lib.MODE_JOINT_TORQUE or self.coupling or self.chunk_samples:
+                raise NotImplementedError("row_blocks: joint-torque regressor of a tree, W resident (no chunk_samples)")
+            rps_in = len(self.row_blocks)
+        else:
+            rps_in = rps
         if tau is not None:
             tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(-1)
-            if tau.shape[0] != rps * len(q):
+            if tau.shape[0] != rps_in * len(q):
                 raise ValueError("tau must have rows_per_sample * N = %d * %d = %d entries; got %d"
-                                 % (rps, len(q), rps * len(q), tau.shape[0]))
+                                 % (rps_in, len(q), rps_in * len(q), tau.shape[0]))
+            if self.row_blocks is not None:  # block i of the caller's tau belongs to dof row_blocks[i]
+                full = np.zeros(rps * len(q))
+                for i, b in enumerate(self.row_blocks):
+                    full[b * len(q):(b + 1) * len(q)] = tau[i * len(q):(i + 1) * len(q)]
+                tau = full
         N, d_q, d_v, d_a = _samples_to_device(self.robot.model, q, v, a)  # raises ValueError on a shape mismatch
         d_tau = None if tau is None else _lib.DeviceArray.from_host(tau)
         # Tree models: the generic regressor kernel takes one sample per lane, and in the reference's sample-major arrays a
@@ -147,7 +181,7 @@ class IdentificationPipeline:
         # (their kernel reads 48-byte runs per lane).
         self._in_flags, self.repack_ms = 0, 0.0
         m = self.robot.model
-        if N > 0 and not (self.robot.device_model().is_chain() and mode == _lib.MODE_JOINT_TORQUE) and not self.coupling:
+        if N > 0 and not (self._handle().is_chain() and mode == _lib.MODE_JOINT_TORQUE) and not self.coupling:
             import time
             _lib.synchronize()
             t0 = time.perf_counter()
@@ -311,7 +345,7 @@ class IdentificationPipeline:
         ex = self.exchange
         # K1 (+ fused column norms)
         mode, flags, ft_mask = self._flags()
-        handle = self.robot.device_model()
+        handle = self._handle()
         if self.W is None:  # HBM buffers are allocated once and reused by every step
             self._kept_cache = None
             self._n_expected = -1
@@ -324,6 +358,17 @@ class IdentificationPipeline:
             wcols = 16 * (self.robot.model.njoints - 1) if self._padded else ncols
             m = self.robot.model
             self._compact = None
+            # external wrench on a free-flyer root: links that cannot have a non-zero entry in any of the six row blocks
+            # (massless bodies, regressor.py:36-39; human model: 21 of 40) get no columns in the resident W -- their columns are
+            # eliminated whatever the samples (figh.h, FIGH_FLAG_LINK_COMPACT: 304 instead of 640 columns, which is what lets
+            # 1e7 human samples stay resident)
+            self._link_pos = self._d_link_pos = None
+            if self._padded and self.w_layout != "link-padded":
+                layout = _lib.regressor_link_layout(handle, mode, flags & 7, ft_mask)
+                if layout is not None and 0 < layout[1] < m.njoints - 1:
+                    self._link_pos = layout[0].astype(np.int64)
+                    self._d_link_pos = _lib.DeviceArray.from_host(layout[0])
+                    wcols = 16 * layout[1]
             if (self.w_layout == "block-compact" and self._padded and mode == _lib.MODE_JOINT_TORQUE
                     and m.nv == m.njoints - 1 and self.N >= 64):
                 sizes = self._subtree_sizes()
@@ -334,6 +379,10 @@ class IdentificationPipeline:
                             raise RuntimeError("block-compact W needs depth-first joint numbering")
                         jid = m.parents[jid]
                 ld = 16 * sizes
+                if self.row_blocks is not None:  # blocks without measurements are not stored at all
+                    keep = np.zeros(m.nv, dtype=bool)
+                    keep[self.row_blocks] = True
+                    ld = np.where(keep, ld, 0)
                 off = self.N * np.concatenate([[0], np.cumsum(ld)[:-1]])
                 self._compact = (off.astype(np.int64), ld.astype(np.int32))
                 self.W = GpuMatrix(_lib.DeviceArray((int(self.N * ld.sum()),), np.float64), rows_per_sample * self.N, wcols,
@@ -372,15 +421,22 @@ class IdentificationPipeline:
             self._tree_blocks = bool(structured and self._padded)
             if self._compact is not None and not self._tree_blocks:
                 raise RuntimeError("block-compact W needs the per-row-block TSQR")
+            if self.row_blocks is not None and not self._tree_blocks:
+                raise NotImplementedError("row_blocks needs the per-row-block TSQR: joint-torque regressor of a tree of "
+                                          "single-dof joints with at least 64 samples")
             self._block_cache = None
         W, d_colsq, lib = self.W, self._d_colsq, _lib.load()
+        if (self.fuse and self._fused_kept is None and not self._padded and self.N >= 4096
+                and handle.is_chain() and mode == _lib.MODE_JOINT_TORQUE and not self.coupling):
+            self._learn_kept_set(handle, mode, flags, ft_mask)
         if self.fuse and self._fused_kept is not None and not self._padded:
             out = self._run_fused(handle, flags, strings)
             if out is not None:
                 return out
         if self._padded:
             _lib.regressor_build_padded(handle, mode, flags | (_lib.FLAG_ZEROS_PRESENT if self._zeros_once else 0)
-                                        | (_lib.FLAG_COMPACT_BLOCKS if self._compact is not None else 0), ft_mask,
+                                        | (_lib.FLAG_COMPACT_BLOCKS if self._compact is not None else 0)
+                                        | (_lib.FLAG_LINK_COMPACT if self._link_pos is not None else 0), ft_mask,
                                         self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         else:
             _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
@@ -394,13 +450,16 @@ class IdentificationPipeline:
             nc = n + (1 if with_tau else 0)
             local = not getattr(ex, "collective", True)
             blocks = None
-            if getattr(self, "_tree_blocks", False) and (nc > 80 or self._compact is not None):
+            if getattr(self, "_tree_blocks", False) and (nc > 80 or self._compact is not None or self.row_blocks is not None):
                 blocks = self._block_lists(ncols, stride)
+                if blocks is None and self.row_blocks is not None and n > 0:
+                    raise RuntimeError("row_blocks: no kept mask to build the column lists from")
             if self._compact is not None and blocks is None and n > 0:
                 raise RuntimeError("block-compact W: no kept mask to build the column lists from")
-            if split:
+            if split or self._link_pos is not None:  # (nf = 0: the plain pass, through the entry that takes the link map)
                 _lib.tsqr_selected_wrench(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, nf, self.d_tau,
-                                          self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R)
+                                          self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R,
+                                          d_link_pos=self._d_link_pos)
             elif blocks is not None:
                 coff, cld = self._compact if self._compact is not None else (None, None)
                 _lib.tsqr_selected_blocks(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, blocks[1],
@@ -451,8 +510,52 @@ class IdentificationPipeline:
         if self.fuse and not self._padded and self._compact is None and (
                 self._fused_kept is None or not np.array_equal(self._fused_kept[0], kept_mask)):
             kept = np.flatnonzero(kept_mask).astype(np.int32)
-            self._fused_kept = (kept_mask.copy(), _lib.DeviceArray.from_host(kept), len(kept))
-        return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, W.rows * ex.world_size, strings)
+            buf = getattr(self, "_d_kept_buf", None)
+            if buf is None or buf.size < ncols:
+                buf = self._d_kept_buf = _lib.DeviceArray((ncols,), np.int32)
+            _lib.check(lib.figh_memcpy_h2d(buf.ptr, kept.ctypes.data, kept.nbytes))
+            self._fused_kept = (kept_mask.copy(), buf, len(kept))
+        rows_mine = W.rows if self.row_blocks is None else len(self.row_blocks) * self.N
+        return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, rows_mine * ex.world_size, strings)
+
+    def forget(self):
+        """Drop everything the pipeline has learnt from earlier passes (kept-column set, counts, per-block lists): the next
+        ``run()`` is a FIRST pass again -- what a script that calls the reference's functions once pays
+        (examples/ur10/identification.py:71-83) -- with the HBM buffers still allocated.  bench.py times it as
+        ``ms_first_pass``."""
+        self._fused_kept = None
+        self._kept_cache = None
+        self._n_expected = self._nf_expected = -1
+        self._mask_expected = None
+        self._block_cache = None
+        self._chunk_kept = None
+
+    PREFIX_SAMPLES = 4096
+
+    def _learn_kept_set(self, handle, mode, flags, ft_mask):
+        """First pass of a serial chain: which columns get_index_eliminate (regressor.py:258-279) keeps is a property of the
+        model -- the eliminated columns are structural zeros of the regressor (UR10: 35 of 84) -- so the set is learnt from the
+        first 4096 samples (one K1 launch of a few microseconds into the head of W, which the pass overwrites; the norms are
+        summed over the ranks like those of a full pass) and the full pass runs FUSED over it.  The fused pass verifies the
+        set against the norms of all samples as always; should a column's norm only cross tol_e with more samples, the pass
+        falls back to the two launches and learns the set from them."""
+        ex, W = self.exchange, self.W
+        n0 = min(self.N, self.PREFIX_SAMPLES)
+        _lib.regressor_build(handle, mode, flags, ft_mask, n0, self.d_q, self.d_v, self.d_a, W.buf, W.ld, self._d_colsq)
+        ex.sum_columns_device(self._d_colsq, W.ref_cols)
+        _lib.select_columns(self._d_colsq, W.ref_cols, self.tol_e, 14, self._d_sel)
+        sel = np.empty(2 + 2 * W.ref_cols, dtype=np.int32)
+        _lib.check(_lib.load().figh_memcpy_d2h(sel.ctypes.data, self._d_sel.ptr, sel.nbytes))
+        mask = sel[2 + W.ref_cols:] != 0
+        if not mask.any():
+            return
+        kept = np.flatnonzero(mask).astype(np.int32)
+        buf = getattr(self, "_d_kept_buf", None)
+        if buf is None or buf.size < W.ref_cols:  # (allocated once: hipMalloc synchronises the device)
+            buf = self._d_kept_buf = _lib.DeviceArray((W.ref_cols,), np.int32)
+        _lib.check(_lib.load().figh_memcpy_h2d(buf.ptr, kept.ctypes.data, kept.nbytes))
+        self._fused_kept = (mask.copy(), buf, len(kept))
+        self.prefix_passes = getattr(self, "prefix_passes", 0) + 1
 
     def _run_fused(self, handle, flags, strings):
         """One pass with K1 and the level-0 TSQR in one launch over the kept-column list of the previous pass
@@ -548,12 +651,17 @@ class IdentificationPipeline:
             _lib.block_rows_residuals(tri, row_off, nc, _lib.DeviceArray.from_host(v), d_r2)
             r2 = np.asarray(ex.sum_columns(d_r2, nblocks + 1))
             sig2 = r2[:nblocks] / r2[nblocks]
+            if self.row_blocks is not None:  # (blocks without measurements: no rows in the stack, no variance)
+                inactive = counts == 0
+                sig2 = np.where(inactive, 1.0, sig2)
             d_cols = _lib.DeviceArray.from_host(np.r_[base, n].astype(np.int32))
             _lib.tsqr(tri, int(row_off[-1]), nc, d_cols, nb_par + 1, None, np.repeat(1.0 / np.sqrt(sig2), counts), d_Rw)
+            if self.row_blocks is not None:
+                sig2 = sig2[self.row_blocks]
             source = "per-row-block triangles"
         else:
-            if self._compact is not None:
-                raise RuntimeError("block-compact W without per-row-block triangles")
+            if self._compact is not None or self.row_blocks is not None:
+                raise RuntimeError("block-compact W / row_blocks without per-row-block triangles")
             d_cols = _lib.DeviceArray.from_host(np.asarray(self.device_columns(kept[base]), dtype=np.int32))
             d_est = _lib.DeviceArray((W.rows,), np.float64)
             _lib.matvec(W.buf, W.rows, W.ld, d_cols, nb_par, _lib.DeviceArray.from_host(phi_b), d_est)
@@ -607,7 +715,11 @@ class IdentificationPipeline:
         kept = np.flatnonzero(mask)
         link, slot = kept // 14, kept % 14
         counts, cols, pos, ccols = [], [], [], []
+        active = None if self.row_blocks is None else set(self.row_blocks)
         for j in range(nb):
+            if active is not None and j not in active:  # no measurements on this joint: the block takes no part
+                counts.append(-1)
+                continue
             in_block = (anc[j][np.minimum(link, nb - 1)] & (link < nb) & (slot < 10)) | ((link == j) & (slot >= 10))
             p = np.flatnonzero(in_block)
             counts.append(len(p))
@@ -648,6 +760,11 @@ class IdentificationPipeline:
             raise ValueError("block-compact W has no global column numbering: row block j is its own N x 16 |subtree_j| "
                              "matrix (pipe.W.compact = (element offsets, leading dimensions))")
         c = np.asarray(ref_cols, dtype=np.int64)
+        if getattr(self, "_link_pos", None) is not None:  # link-compact: only links with entries have a segment
+            pos = self._link_pos[c // 14]
+            if (pos < 0).any():
+                raise ValueError("link-compact W holds no columns for links without entries (structural zeros)")
+            return pos * 16 + c % 14
         return (c // 14) * 16 + c % 14 if getattr(self, "_padded", False) else c
 
     def _place_W(self, rows, cols, handle, mode, flags, ft_mask):

@@ -61,7 +61,17 @@ enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, 
         * link-padded row, ld_j = 16 size_j) at element offset N * (ld_0 + .. + ld_{j-1}).  Everything outside the window is
         * a structural zero that is neither stored nor read (figh_tsqr_selected_blocks with block offsets).  ldw is ignored;
         * d_colsq keeps the reference's column numbering.  TIAGo: 7.9 instead of 73.7 GB per 1e6 samples. */
-       FIGH_FLAG_COMPACT_BLOCKS = 2048 };
+       FIGH_FLAG_COMPACT_BLOCKS = 2048,
+       /* figh_regressor_build_padded only, external-wrench regressor of a model with a free-flyer root: d_W is LINK-COMPACT --
+        * only the links that can have a non-zero entry at all keep their 16-column segment (a body with mass and a selected
+        * wrench component, or every link when a friction / inertia / offset flag is set; regressor.py:36-39, :142-169), in
+        * link order: segment of link l at column 16 pos[l], ldw >= 16 * (number of such links), pos from
+        * figh_regressor_link_layout.  The other links' columns -- structural zeros in all six row blocks, eliminated by
+        * get_index_eliminate (regressor.py:258-279) whatever the samples -- are neither written nor read: human model
+        * 19 x 16 = 304 instead of 40 x 16 = 640 columns (146 instead of 307 GB for 1e7 samples).  d_colsq keeps the
+        * reference's numbering (exact zeros for the dropped links).  Consumers take the map as d_link_pos
+        * (figh_tsqr_selected_wrench). */
+       FIGH_FLAG_LINK_COMPACT = 4096 };
 
 typedef struct figh_model_s *figh_model_t;
 
@@ -130,6 +140,14 @@ int figh_model_create(int njoints, const int32_t *parents, const int32_t *jtype,
                       const double *placement, const int32_t *idx_q, const int32_t *idx_v, const double *gravity,
                       const int32_t *body_mask, figh_model_t *out);
 int figh_model_destroy(figh_model_t model);
+/* ACTIVE JOINTS (examples/tiago/identification.py:148-187, :406-424: the script builds the regressor of all 24 dofs,
+ * eliminates columns on the norms of the full matrix, and then decimates, stacks and factors only the row blocks of the
+ * eight joints that carry measurements, act_idxv).  h_rows: the n dof indices whose row blocks figh_regressor_build_padded
+ * STORES from now on (joint-torque mode of a tree of single-dof joints; link-padded or block-compact layout -- in the
+ * block-compact one the other blocks take no memory at all, ld_j = 0); d_colsq keeps covering every row block, so
+ * get_index_eliminate sees the reference's norms.  n <= 0 / NULL: every row block again (the default).  The chain kernel,
+ * figh_regressor_build and the external-wrench mode ignore the setting. */
+int figh_model_set_active_rows(figh_model_t model, const int32_t *h_rows, int n);
 /* number of rows per sample and number of columns of the stacked regressor for (mode, flags) */
 int figh_regressor_shape(figh_model_t model, int mode, int flags, int *rows_per_sample, int *ncols);
 
@@ -152,6 +170,11 @@ int figh_regressor_build(figh_model_t model, int mode, int flags, int ft_mask, i
  * (14 (njoints-1) entries).  figh_tsqr / figh_matvec / figh_gather_cols take such a W through their column lists. */
 int figh_regressor_build_padded(figh_model_t model, int mode, int flags, int ft_mask, int64_t N, const double *d_q,
                                 const double *d_v, const double *d_a, double *d_W, int64_t ldw, double *d_colsq);
+/* The link -> segment map of FIGH_FLAG_LINK_COMPACT for (model, mode, flags, ft_mask): h_link_pos[l] (njoints - 1 entries,
+ * host) = position of link l + 1's segment, -1 for a link without one; *nlive = number of links with a segment.
+ * FIGH_ERR_UNSUPPORTED when the layout does not apply (not an external-wrench regressor on a free-flyer root).  Which
+ * links drop out follows from the model alone -- id_inertias of regressor.py:36-39 -- not from the samples. */
+int figh_regressor_link_layout(figh_model_t model, int mode, int flags, int ft_mask, int32_t *h_link_pos, int *nlive);
 
 /* figh_repack_samples: d_dst[(t * width + k) * 64 + l] = d_src[min(64 t + l, N - 1) * width + k] -- a sample-major N x width
  * array (q, v or a exactly as the reference holds them) re-laid per tile of 64 samples, value-major inside the tile, the
@@ -262,10 +285,12 @@ int figh_regressor_tsqr_fused(figh_model_t model, int flags, int64_t N, const do
  * 2 m n^2 flops for half of W), and the torque rows by a launch whose first workgroup starts from the force rows'
  * triangle.  Same outputs as figh_tsqr_selected (R is the R factor of the whole W[:, kept | tau]); nf_expected is the
  * number of kept columns c with c % 14 >= 6 -- the caller derives it from the same mask as n_expected and verifies both
- * afterwards.  nf_expected <= 0, at most 80 columns or rows % 6 != 0: plain figh_tsqr_selected. */
+ * afterwards.  nf_expected <= 0, at most 80 columns or rows % 6 != 0: plain figh_tsqr_selected.  d_link_pos (nullable,
+ * device, njoints - 1 int32): d_W is link-compact (FIGH_FLAG_LINK_COMPACT), reference column 14 l + s is column
+ * 16 d_link_pos[l] + s. */
 int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nf_expected, const double *d_tau, double tol_qr,
-                              int32_t *d_sel, double *d_R_out);
+                              int32_t *d_sel, double *d_R_out, const int32_t *d_link_pos);
 /* figh_tsqr_selected for the joint-torque regressor of a tree of single-dof joints (regressor.py:45-87, rows j*N + i): row
  * block j only involves the links of joint j's subtree and the Ia / fv / fs / off columns of link j itself; all other
  * entries are structural zeros.  Row block j (rows / nblocks rows) is factored over its own column list -- h_counts[j]
@@ -277,7 +302,10 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
  * The nblocks embedded triangles are stacked compactly -- block j contributes its h_counts[j] (+ 1 with tau) rows over the
  * nc kept columns [+ tau] -- and factored as one small tall matrix.  d_block_tri (nullable; room for
  * (sum_j (h_counts[j] + 1) + nc + 1) nc doubles) receives that stack, for a weighted solve afterwards
- * (figh_block_rows_residuals, then figh_tsqr over its rows with one weight per row: W itself is not read again). */
+ * (figh_block_rows_residuals, then figh_tsqr over its rows with one weight per row: W itself is not read again).
+ * h_counts[j] == -1: row block j is INACTIVE -- neither its rows of W nor its rows of tau take part (the joints without
+ * measurements of examples/tiago/identification.py:148-187; figh_model_set_active_rows keeps them out of W as well); it has
+ * no entries in d_cols / d_pos and no rows in the stack. */
 int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nblocks, const int32_t *h_counts, const int32_t *d_cols,
                               const int32_t *d_pos, const int64_t *h_block_off, const int32_t *h_block_ld,

@@ -209,3 +209,30 @@ def test_numpy_oracle_reproduces_reference_qr_pivoting(golden):
     W_b0, bp0 = oracle_np.qr_pivoting(golden["tau"], W[:, keep][:, golden["idx_base"]],
                                       [golden.meta["params_r"][i] for i in golden["idx_base"]])
     assert list(W_b0.shape) == ref["full_rank_result"]["W_b_shape"] and len(bp0) == 0
+
+
+def test_tiago_active_joint_fixture_is_consistent_with_the_oracle():
+    """tests/golden/tiago_active.* (made by the reference's decimate_data / double_QR, oracle/gen_golden_tiago_active.py): the
+    ``raw`` case is reproduced by the oracle's own regressor + the oracle's restatement of the elimination and of double_QR on
+    the stacked active row blocks -- the fixture and the oracle agree on what "active joints" means."""
+    import json
+    from conftest import GOLD, Golden
+    g = Golden("cfg3_tiago")
+    with open(os.path.join(GOLD, "tiago_active.json")) as f:
+        meta = json.load(f)
+    z = np.load(os.path.join(GOLD, "tiago_active.npz"))
+    act = meta["act_idxv"]
+    assert act == [12, 13, 14, 15, 16, 17, 18, 19]  # torso_lift + arm_1..7 in Pinocchio's dof numbering (SURVEY A.4)
+    q, v, a, tau = z["raw_q"], z["raw_v"], z["raw_a"], z["raw_tau"]
+    N = len(q)
+    W = oracle_np.build_regressor_basic(g.flat(), q, v, a, g.param)
+    norms = np.einsum("ij,ij->j", W, W)
+    idx_e = np.flatnonzero(norms < meta["tol_e"]).tolist()
+    assert idx_e == z["raw_idx_e"].tolist()
+    kept = [c for c in range(W.shape[1]) if c not in set(idx_e)]
+    Wa = np.vstack([W[b * N:(b + 1) * N][:, kept] for b in act])
+    assert Wa.shape[0] == int(z["raw_rows"][0])
+    colsq = np.einsum("ij,ij->j", Wa, Wa)
+    assert np.abs(colsq - z["raw_W_rf_colsq"]).max() <= 1e-10 * colsq.max()
+    R = np.linalg.qr(Wa, mode="r")
+    assert np.flatnonzero(np.abs(np.diag(R)) > 1e-8).tolist() == z["raw_idx_base"].tolist()
