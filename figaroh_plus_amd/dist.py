@@ -447,6 +447,53 @@ class RcclExchange:
         self._lib.load().figh_comm_destroy()
 
 
+def allreduce_normal_terms(exchange, colsq, G, g, tau_sq, rows):
+    """Collective (1) of SURVEY.md section 8e: ``[colsq | G | W^T tau | tau^T tau | rows]`` packed into ONE fp64 buffer and
+    summed over the ranks with one all-reduce -- everything the normal-equation consumers of the path need from all shards:
+    the elimination (``colsq``, regressor.py:258-279), the SIP quadratic program's data terms (identification_tools.py:528-531:
+    ``W^T W``, ``W^T tau``) and the residual variance of ``relative_stdev`` (:204-234: ``tau^T tau - 2 phi^T W^T tau + phi^T W^T
+    W phi`` over ``rows - n`` degrees of freedom).  n^2 + 2 n + 2 doubles for n columns (57 KB .. 2.5 MB): one latency-bound
+    message.  (NOT for the rank decision: ``|R_kk| > tol_qr`` needs the Householder factors, see ``stack_triangles``.)
+
+    Arguments are this rank's host arrays / numbers (``colsq`` may be None); returns the summed (colsq, G, g, tau_sq, rows).
+    Host-staged exchanges sum the pack on the host; ``RcclExchange`` sums it in HBM."""
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    n = G.shape[0]
+    ncs = 0 if colsq is None else len(colsq)
+    pack = np.concatenate([np.zeros(0) if colsq is None else np.asarray(colsq, dtype=np.float64), G.reshape(-1),
+                           np.asarray(g, dtype=np.float64).reshape(-1), [float(tau_sq), float(rows)]])
+    if exchange is None or exchange.world_size == 1:
+        total = pack
+    elif hasattr(exchange, "allreduce_sum_host"):
+        total = np.asarray(exchange.allreduce_sum_host(pack))
+    else:
+        from . import _lib
+
+        d = _lib.DeviceArray.from_host(pack)
+        total = np.asarray(exchange.sum_columns(d, pack.size))
+        d.free()
+    colsq_t = None if colsq is None else total[:ncs].copy()
+    G_t = total[ncs:ncs + n * n].reshape(n, n).copy()
+    g_t = total[ncs + n * n:ncs + n * n + n].copy()
+    return colsq_t, G_t, g_t, float(total[-2]), float(total[-1])
+
+
+def allgather_max(exchange, value):
+    """max over the ranks of a host scalar (``sf2 = 1 / (max(tau) len(tau))`` of the SIP program needs the global maximum):
+    a gather of one number per rank through the exchange."""
+    if exchange is None or exchange.world_size == 1:
+        return float(value)
+    if hasattr(exchange, "allgather_host"):
+        return float(np.max(exchange.allgather_host(np.array([float(value)]))))
+    from . import _lib
+
+    d = _lib.DeviceArray.from_host(np.array([float(value)]))
+    stack, count = exchange.stack_triangles(d, 1)
+    out = np.empty(count)
+    _lib.check(_lib.load().figh_memcpy_d2h(out.ctypes.data, stack.ptr, out.nbytes))
+    return float(out.max())
+
+
 def rccl_preflight():
     """Local check, no communication: (ok, reason).  librccl loads with every symbol and a HIP device is present."""
     from . import _lib

@@ -140,6 +140,20 @@ def relative_stdev(W_b, phi_b, tau):
     return relative_percent(np.sqrt(std_x_sqr), phi_b)  # (an estimate of exactly zero: inf, like the reference's division)
 
 
+def relative_stdev_from_normal_terms(G, g, tau_sq, rows, phi_b):
+    """``relative_stdev`` (identification_tools.py:204-234) from the normal-equation terms of the base regressor -- G = W_b^T
+    W_b, g = W_b^T tau, tau^T tau, row count -- as ``dist.allreduce_normal_terms`` sums them over sample shards:
+    ||tau - W_b phi||^2 = tau^T tau - 2 phi^T g + phi^T G phi, C = sigma^2 G^-1.  For well-conditioned base regressors (the
+    difference of large numbers loses cond(W_b)^2 eps of the residual; the triangle form of :func:`relative_stdev` does
+    not)."""
+    phi_b = np.asarray(phi_b, dtype=np.float64)
+    G = np.asarray(G, dtype=np.float64)
+    res2 = float(tau_sq - 2.0 * phi_b @ g + phi_b @ G @ phi_b)
+    sig_ro_sqr = res2 / (rows - phi_b.shape[0])
+    C_x = sig_ro_sqr * np.linalg.inv(G)
+    return relative_percent(np.sqrt(np.diag(C_x)), phi_b)
+
+
 def block_residual_sqnorms(tau_meas, tau_est, nblocks):
     """Per-joint squared residual norms ||tau_j - tau_est_j||^2 on the device.  ``nblocks``: a number of
     equal blocks, or the list of block lengths (joints keep different numbers of rows after the zero-velocity
@@ -538,13 +552,18 @@ def decimate_joint_blocks(W, tau, nblocks, q=10, stages=2, blocks=None):
 
 
 @host_tail
-def sip_qp_terms(robot, q, v, a, tau, param, col_idx, phi_ref, alpha, coupling=False):
+def sip_qp_terms(robot, q, v, a, tau, param, col_idx, phi_ref, alpha, coupling=False, exchange=None):
     """The data terms of ``calculate_standard_parameters`` (identification_tools.py:466-572, the SIP quadratic
     program): ``P = (1-alpha) sf1 I + alpha sf2 W^T W`` and ``r = -((1-alpha) sf1 phi_ref + alpha sf2 W^T tau)`` with
     ``sf1 = 1 / (max(phi_ref) len(phi_ref))``, ``sf2 = 1 / (max(tau) len(tau))`` (``:528-531``), for the columns
     ``col_idx`` of the regressor of the samples (q, v, a).  W^T W and W^T tau come from ``figh_regressor_gram`` (formed
     from the Householder triangle, W never stored); the constraint matrices G, h and the QP solve (quadprog) stay with
-    the caller.  Returns (P, r)."""
+    the caller.  Returns (P, r).
+
+    ``exchange`` (figaroh_plus_amd.dist, one process per GPU): (q, v, a, tau) are THIS rank's shard of the samples; the
+    Gram terms of all shards are summed in one all-reduce (``dist.allreduce_normal_terms``: collective (1) of SURVEY 8e),
+    ``max(tau)`` and ``len(tau)`` are taken over all ranks, and every rank returns the same (P, r) as a single process
+    would on the whole sample set."""
     from ..tools.regressor import _samples_to_device, regressor_flags
 
     mode, flags, ft_mask = regressor_flags(param, coupling)
@@ -558,9 +577,14 @@ def sip_qp_terms(robot, q, v, a, tau, param, col_idx, phi_ref, alpha, coupling=F
     N, d_q, d_v, d_a = _samples_to_device(robot.model, q, v, a)
     d_idx = _lib.DeviceArray.from_host(cols)
     d_tau = _lib.DeviceArray.from_host(tau)
-    G, g, _ = _lib.regressor_gram(dm, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau)
+    G, g, tt = _lib.regressor_gram(dm, mode, flags, ft_mask, N, d_q, d_v, d_a, d_idx, n, d_tau)
+    tau_max, tau_len = np.max(tau), len(tau)
+    if exchange is not None and exchange.world_size > 1:
+        from ..dist import allgather_max, allreduce_normal_terms
+        _, G, g, tt, tau_len = allreduce_normal_terms(exchange, None, G, g, tt, tau_len)
+        tau_max = allgather_max(exchange, tau_max)
     sf1 = 1 / (np.max(phi_ref) * len(phi_ref))
-    sf2 = 1 / (np.max(tau) * len(tau))
+    sf2 = 1 / (tau_max * tau_len)
     P = (1 - alpha) * sf1 * np.eye(n) + alpha * sf2 * G
     r = -((1 - alpha) * sf1 * phi_ref + sf2 * alpha * g)
     return P, r

@@ -375,3 +375,82 @@ def test_socket_rendezvous_rejects_strangers(tmp_path, secret):
         c.close()
     for r in (0, 2):
         assert open(tmp_path / ("r%d.txt" % r)).read() == "[0, 10, 20]"
+
+
+def _normal_terms_worker(rank, world, port, out_dir, plane):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_c
+    from figaroh_plus_amd import dist as fd
+    from figaroh_plus_amd.identification.identification_tools import relative_stdev_from_normal_terms
+    from figaroh_plus_amd.model import Model
+
+    if plane == "torch":
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ex = fd.TorchExchange()
+    else:
+        ex = fd.SocketExchange(fd.SocketGroup.from_env())
+    g = np.load(os.path.join(GOLD, "cfg2_ur10.npz"))
+    flat = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", "ur10.json")).to_flat()
+    om = oracle_c.OracleModel(flat)
+    N = len(g["q_big"])
+    # unequal shards on purpose (the divisor of the variance is the SUMMED row count)
+    cut = [0, 150, N] if world == 2 else [0, 100, 250, N]
+    lo, hi = cut[rank], cut[rank + 1]
+    W = om.build_regressor_basic(g["q_big"][lo:hi], g["v_big"][lo:hi], g["a_big"][lo:hi], 0, 0)
+    tau = np.ascontiguousarray(g["tau"].reshape(6, N)[:, lo:hi]).reshape(-1)
+    keep = [i for i in range(W.shape[1]) if i not in set(g["idx_e"].tolist())]
+    Wb = W[:, keep][:, g["idx_base"]]
+    colsq, G, gv, tt, rows = fd.allreduce_normal_terms(ex, oracle_c.colsq(W), Wb.T @ Wb, Wb.T @ tau, tau @ tau, len(tau))
+    tmax = fd.allgather_max(ex, np.max(tau))
+    phi = np.linalg.solve(G, gv)
+    std = relative_stdev_from_normal_terms(G, gv, tt, rows, phi)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), colsq=colsq, G=G, g=gv, tt=tt, rows=rows, tmax=tmax, phi=phi, std=std)
+    ex.barrier()
+    if plane == "torch":
+        dist.destroy_process_group()
+    else:
+        ex.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("plane,world", [("torch", 2), ("socket", 3)])
+def test_normal_terms_allreduce_matches_single_process(tmp_path, oracle_lib, plane, world):
+    """Collective (1) of SURVEY 8e: [colsq | G | W^T tau | tau^T tau | rows] summed over UNEQUAL sample shards in one
+    all-reduce (dist.allreduce_normal_terms) equals the single-process quantities on the whole sample set -- bit-identical
+    on every rank -- and what its consumers derive from it: the normal-equation solution (the golden pinv solution to 1e-8),
+    relative_stdev (identification_tools.py:204-234) and max(tau) of the SIP scaling (:528-531)."""
+    import multiprocessing as mp
+    import oracle_np
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_normal_terms_worker, args=(r, world, port, str(tmp_path), plane)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+        assert p.exitcode == 0
+    res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    g = np.load(os.path.join(GOLD, "cfg2_ur10.npz"))
+    for r in res[1:]:
+        for k in ("colsq", "G", "g", "tt", "rows", "tmax", "phi", "std"):
+            assert np.array_equal(r[k], res[0][k]), k
+    r0 = res[0]
+    assert np.abs(r0["colsq"] - g["colsq_big"]).max() <= 1e-12 * g["colsq_big"].max()
+    from figaroh_plus_amd.model import Model
+    flat = Model.from_flat(os.path.join(ROOT, "figaroh_plus_amd", "models", "ur10.json")).to_flat()
+    W = oracle_lib.OracleModel(flat).build_regressor_basic(g["q_big"], g["v_big"], g["a_big"], 0, 0)
+    tau = g["tau"]
+    assert float(r0["rows"]) == len(tau) and abs(float(r0["tt"]) - tau @ tau) <= 1e-12 * (tau @ tau)
+    assert float(r0["tmax"]) == np.max(tau)
+    assert np.abs(r0["phi"] - g["phi_pinv"]).max() <= 1e-8 * np.abs(g["phi_pinv"]).max()
+    if W is not None:
+        keep = [i for i in range(W.shape[1]) if i not in set(g["idx_e"].tolist())]
+        Wb = W[:, keep][:, g["idx_base"]]
+        assert np.abs(r0["G"] - Wb.T @ Wb).max() <= 1e-12 * np.abs(r0["G"]).max()
+        ref_std = oracle_np.relative_stdev(Wb, r0["phi"], tau)
+        assert np.abs(r0["std"] - ref_std).max() <= 0.011
