@@ -91,28 +91,33 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
     for (int cc = 0; cc < LIVE; ++cc) asm volatile("" : "+v"(Rk[cc]));
     asm volatile("" : "+v"(alpha));
     const double sigma = row_bcast<KK>(d[0]);
-    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
     // s = sqrt(alpha^2 + sigma), beta = -sign(alpha) s, inv = 1/(alpha - beta) = sign(alpha)/(|alpha| + s),
     // tfac = (beta - alpha)/beta = (|alpha| + s)/s: v_rsq_f64 / v_rcp_f64 seeds (~2^-24) + ONE third-order step each
-    // (y (1 + e/2 + 3e^2/8), e = 1 - q y^2: error e^3; r (1 + e + e^2), e = 1 - d r) instead of two Newton steps:
-    // 5 + 3 dependent operations instead of 7 + 4
+    // (y (1 + e/2 + 3e^2/8), e = 1 - q y^2: error e^3; r (1 + e + e^2), e = 1 - d r) instead of two Newton steps.
+    // Round 5: (i) the reciprocal starts from the UNCORRECTED rsq seed and is corrected against the accurate |alpha| + s
+    // (householder_scalars4, figh_wave.h): the v_rcp_f64 runs beside the correction of rs, 26 ticks off the dependent chain;
+    // (ii) the chain starts BEFORE the zero-column test -- the ballot -> branch round trip (~60 ticks) runs in its shadow; a
+    // zero column discards inf / NaN.  The asm pins the chain in front of the branch (the compiler sinks it otherwise).
     const double q2 = fma(alpha, alpha, sigma);
     // NULL PIVOT (dlarfg's H = I rule with a threshold, figh_tsqr_null_pivot_tol): the column is zero to working accuracy
     // at and below the diagonal -- a linearly dependent column of the regressor, whose residual is rounding noise in every
     // tile.  Its norm moves into R_kk (which therefore keeps the running residual norm of the column: the test is on
     // alpha^2 + sigma, so at most null2 of a column's energy is ever folded), the column leaves the tile, and no reflector
     // is formed: no trailing updates.  q2 is the same number in every lane.
-    double rs = __builtin_amdgcn_rsq(q2);
+    const double rs0 = __builtin_amdgcn_rsq(q2);
+    double ri = __builtin_amdgcn_rcp(fma(q2, rs0, fabs(alpha)));
+    double rs;
     {
-        const double e = fma(-(q2 * rs), rs, 1.0);
-        rs = fma(rs, fma(e, 0.375, 0.5) * e, rs);
+        const double e = fma(-(q2 * rs0), rs0, 1.0);
+        rs = fma(rs0, fma(e, 0.375, 0.5) * e, rs0);
     }
     const double dsum = fma(q2, rs, fabs(alpha));  // |alpha| + s
-    double ri = __builtin_amdgcn_rcp(dsum);
     {
         const double e = fma(-dsum, ri, 1.0);
         ri = fma(ri, fma(e, e, e), ri);
     }
+    asm volatile("" : "+v"(ri), "+v"(rs));
+    if (__builtin_amdgcn_ballot_w64(sigma != 0.0) == 0) return;  // column zero below the triangle: H = I (dlarfg)
     const double inv = copysign(ri, alpha);
     const double tfac = dsum * rs;
     const bool live = __builtin_amdgcn_ballot_w64(q2 > S.null2) != 0;

@@ -143,8 +143,11 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
         TColumn<8, KK>::load(tr, Tl + c * kLdt);
         TColumn<8, KK>::dot(acc0, acc1, tr, vg);
     }
+    // (round 5: the reciprocal of the scalars runs beside the rsq correction, householder_scalars4; starting the whole chain
+    // in front of the test -- as the register-tile step now does -- costs this kernel 12 .. 16 more bytes of scratch in the
+    // panel chain and gained nothing: TALOS level 0 2 x 51.4 ms against 82.4 + 18.9)
     double inv, tfac;
-    householder_scalars3(alpha, sigma, inv, tfac);
+    householder_scalars4(alpha, sigma, inv, tfac);
     // w_c = tau (R_kc + v^T X_c); the pivot lane gets w = alpha - beta, i.e. R_kk = alpha - w = beta
     // (frozen columns c < KK: w = 0; their row entry rk is a structural zero of the diagonal block and stays one)
     const double wj = (c >= KK) ? (rk + d * inv) * tfac : 0.0;

@@ -100,4 +100,26 @@ __device__ __forceinline__ void householder_scalars3(const double alpha, const d
     tfac = dsum * rs;
 }
 
+// The same scalars with the reciprocal started from the UNCORRECTED rsq seed: dsum0 = q2 rs0 + |alpha| is 2^-23 accurate, and
+// so is rcp(dsum0) as an approximation of 1 / dsum -- its third-order correction is taken against the accurate dsum (e = 1 -
+// dsum ri0 ~ 1e-7, error e^3), so the v_rcp_f64 (26 ticks) runs beside the correction of rs instead of behind it: 77 instead
+// of 103 ticks from the rsq to inv on the dependent chain of a column step (tools/microbench/latency.hip for the latencies).
+__device__ __forceinline__ void householder_scalars4(const double alpha, const double sigma, double &inv, double &tfac) {
+    const double q2 = fma(alpha, alpha, sigma);
+    const double rs0 = __builtin_amdgcn_rsq(q2);
+    double ri = __builtin_amdgcn_rcp(fma(q2, rs0, fabs(alpha)));
+    double rs;
+    {
+        const double e = fma(-(q2 * rs0), rs0, 1.0);
+        rs = fma(rs0, fma(e, 0.375, 0.5) * e, rs0);
+    }
+    const double dsum = fma(q2, rs, fabs(alpha));  // |alpha| + s
+    {
+        const double e = fma(-dsum, ri, 1.0);
+        ri = fma(ri, fma(e, e, e), ri);
+    }
+    inv = copysign(ri, alpha);
+    tfac = dsum * rs;
+}
+
 }  // namespace figh

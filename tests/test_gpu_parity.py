@@ -1972,7 +1972,12 @@ def test_null_pivot_rule_never_changes_the_base_set(lib, cfg, sizes):
                 del pipe
             off, on_ = res[False], res[True]
             assert on_["idx_e"] == off["idx_e"] and on_["idx_base"] == off["idx_base"], (cfg, N, seed)
-            assert on_["params_base"] == off["params_base"]
+            # (the regrouping coefficients agree to a few units of their 6-decimal rounding; the expression STRINGS list every
+            # term of at least 1e-6, and with 50 000 random TX40 samples both modes carry a few noise terms of exactly that
+            # size -- different ones -- so the strings are compared where no coefficient sits at the threshold)
+            assert np.abs(on_["beta"] - off["beta"]).max() <= 5e-6
+            if not ((np.abs(off["beta"]) > 0) & (np.abs(off["beta"]) < 1e-5)).any():
+                assert on_["params_base"] == off["params_base"]
             # (TIAGo's base regressor is ill-conditioned -- one base parameter comes out at 4e6 with 0.05 of noise on tau -- and
             # ANY two Householder orders differ by cond(W_b) eps in phi: the fit itself is compared there)
             phi_tol = 1e-6 if cfg == "cfg1_tx40" else 1e-3
