@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../../figaroh_plus_amd/csrc/figh_tsqr_narrow.h"
+#include "../../figaroh_plus_amd/csrc/figh_tsqr_wide_kernel.h"
 
 using namespace figh;
 
@@ -86,11 +87,81 @@ int run(const char *label, double *out, long long *cyc) {
     return 0;
 }
 
+// The PANEL CHAIN of the blocked kernel (wy_factor_panel: 16 dependent column steps on a 64 x 16 chunk) next to what shares
+// its SIMD in tsqr_wy_kernel: nothing, a second panel chain, or a wave of the other workgroup streaming v_mfma_f64_16x16x4
+// (a trailing sweep).  partner: 0 = chain waves only (1 per SIMD), 1 = every chain wave shares its SIMD with a second chain
+// wave, 2 = ... with an MFMA wave.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_panel(double *out, long long *cyc, const int passes, const int partner, const double seed) {
+    __shared__ double rl[8][256], red[8][64], vl[8][64 * 17 + 16 * 17];
+    __shared__ int stop;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) stop = 0;
+    __syncthreads();
+    const int c = lane & 15, g = lane >> 4;
+    const bool chain = wave < 4 || partner == 1;
+    if (chain) {
+        if (partner == 3) __builtin_amdgcn_s_setprio(3);  // (what tsqr_wy_kernel gives the owner of a panel)
+        double keep[16], X[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep[i] = seed + 1e-3 * ((lane * 31 + i * 7) % 97) - 0.04;
+        const long long t0 = __builtin_readcyclecounter();
+        for (int p = 0; p < passes; ++p) {
+            for (int e = lane; e < 256; e += 64) rl[wave][e] = (e / 16 == e % 16) ? 3.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                X[i] = keep[i];
+                asm volatile("" : "+v"(X[i]));
+            }
+            wy_factor_panel<16>(X, rl[wave], red[wave], vl[wave], vl[wave] + 64 * 17, lane, c, g, 0.0);
+        }
+        const long long t1 = __builtin_readcyclecounter();
+        out[threadIdx.x] = X[0] + rl[wave][lane];
+        if (lane == 0) cyc[wave] = t1 - t0;
+        if (wave == 0 && lane == 0) __hip_atomic_store(&stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        f64x4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        double x = seed + lane, y = 0.5 - lane;
+        while (__hip_atomic_load(&stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+            }
+        }
+        out[threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+        if (lane == 0) cyc[wave] = 0;
+    }
+}
+
+int run_panel(double *out, long long *cyc) {
+    const int passes = 300;
+    const char *what[4] = {"alone on its SIMD", "next to a second panel chain", "next to a wave streaming v_mfma_f64_16x16x4",
+                           "next to an MFMA wave, s_setprio 3"};
+    for (int partner = 0; partner < 4; ++partner) {
+        long long best = 1LL << 60;
+        for (int r = 0; r < 3; ++r) {
+            hipLaunchKernelGGL(k_panel, dim3(1), dim3(partner == 0 ? 256 : 512), 0, 0, out, cyc, passes, partner, 1.0 + r);
+            long long h[8];
+            CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+            long long worst = 0;
+            for (int w = 0; w < 4; ++w) worst = h[w] > worst ? h[w] : worst;
+            best = worst < best ? worst : best;
+        }
+        printf("panel chain of the blocked kernel (16 steps on 64 x 16) %-46s %7.1f ticks per column step\n", what[partner],
+               (double)best / (passes * 16));
+    }
+    return 0;
+}
+
 int main() {
     double *out;
     long long *cyc;
     CHECK(hipMalloc(&out, sizeof(double) * 4096));
     CHECK(hipMalloc(&cyc, sizeof(long long) * 64));
+    if (run_panel(out, cyc)) return 1;
     if (run<4, 1>("one chunk, 64-row tile (last panel)", out, cyc)) return 1;
     if (run<8, 1>("one chunk, 128 rows (last panel of two tiles)", out, cyc)) return 1;
     if (run<4, 2>("two chunks, 64-row tile (panels 2, 3)", out, cyc)) return 1;
