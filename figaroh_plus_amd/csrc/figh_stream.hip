@@ -138,6 +138,18 @@ static int regressor_tsqr_impl(figh_model_t model, int mode, int flags, int ft_m
     int nlive = padded ? tree_link_positions(model, mode, flags & 7, ft_mask, link_pos) : -1;
     if (nlive <= 0 || nlive >= model->host.nlinks) nlive = -1;
     if (nlive > 0) {
+        // a caller may list columns of links without entries (identically zero columns: the SIP program passes the inertial
+        // columns of EVERY link, identification_tools.py:528-531): those exist in the link-padded layout only
+        std::vector<int32_t> cols(n);
+        if (d_col_idx) {
+            if (int rc = figh_memcpy_d2h(cols.data(), d_col_idx, sizeof(int32_t) * n)) return rc;
+        } else {
+            for (int c = 0; c < n; ++c) cols[c] = c;
+        }
+        for (int c = 0; c < n && nlive > 0; ++c)
+            if (cols[c] < 0 || cols[c] / 14 >= model->host.nlinks || link_pos[cols[c] / 14] < 0) nlive = -1;
+    }
+    if (nlive > 0) {
         d_link_pos = static_cast<int *>(workspace(sizeof(int) * kMaxJoints, 37));
         if (!d_link_pos) return FIGH_ERR_ALLOC;
         FIGH_HIP(hipMemcpyAsync(d_link_pos, link_pos, sizeof(int) * model->host.nlinks, hipMemcpyHostToDevice, stream()));

@@ -1,7 +1,10 @@
 // Store patterns of the tree regressor kernel (K1'): every wave writes, for each of its 64-sample tiles, NB row blocks x NL
 // link segments of 64 rows x 128 bytes.  Pattern 0: row-major W (row stride ldw * 8 bytes: a store instruction covers eight
 // 128-byte lines 4 KB apart).  Pattern 1: 16-row blocked layout (block = 16 rows x 16 columns = 2 KB contiguous: a store
-// instruction covers 1 KB contiguous).  Pattern 2: whole 8 KB tile contiguous (upper bound).
+// instruction covers 1 KB contiguous).  Pattern 2: whole 8 KB tile contiguous (upper bound).  Pattern 5 (round 5): LANE-OWNED
+// lines -- lane i writes the whole 128-byte line of ITS row with eight consecutive 16-byte stores (each store instruction
+// touches 64 different lines, 16 bytes each; the eight pieces of a line meet in L2): what a sample-per-lane kernel that stages
+// a line in registers would issue.
 //   hipcc --offload-arch=gfx950 -O3 store_pattern.hip -o store_pattern && ./store_pattern
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,6 +22,15 @@ __global__ __launch_bounds__(64) void store_kernel(double *W, long N, int NB, in
             const long rowbase = (long)j * N + 64 * t;
             for (int l = 0; l < NL; ++l) {
                 u32x4 d = {(unsigned)l, (unsigned)j, (unsigned)lane, 0u};
+                if (PAT == 5) {
+                    double *p = W + (rowbase + lane) * ldw + 16 * l;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        if (NT) __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(p + 2 * it));
+                        else *reinterpret_cast<u32x4 *>(p + 2 * it) = d;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const long r = rowbase + 8 * it + rg;
@@ -45,7 +57,7 @@ int main(int argc, char **argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     for (int waves : {2048, 2816}) {
-        for (int pat = 0; pat < 5; ++pat) {  // 3, 4: patterns 0, 1 with ordinary (cached) stores
+        for (int pat = 0; pat < 7; ++pat) {  // 3, 4: patterns 0, 1 with ordinary (cached) stores; 5, 6: lane-owned lines (nt / cached)
             float best = 1e9f;
             for (int rep = 0; rep < 4; ++rep) {
                 hipEventRecord(e0);
@@ -54,6 +66,8 @@ int main(int argc, char **argv) {
                 if (pat == 2) hipLaunchKernelGGL((store_kernel<2, 1>), dim3(waves), dim3(64), 0, 0, W, N, NB, NL, ntiles);
                 if (pat == 3) hipLaunchKernelGGL((store_kernel<0, 0>), dim3(waves), dim3(64), 0, 0, W, N, NB, NL, ntiles);
                 if (pat == 4) hipLaunchKernelGGL((store_kernel<1, 0>), dim3(waves), dim3(64), 0, 0, W, N, NB, NL, ntiles);
+                if (pat == 5) hipLaunchKernelGGL((store_kernel<5, 1>), dim3(waves), dim3(64), 0, 0, W, N, NB, NL, ntiles);
+                if (pat == 6) hipLaunchKernelGGL((store_kernel<5, 0>), dim3(waves), dim3(64), 0, 0, W, N, NB, NL, ntiles);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
