@@ -1981,7 +1981,7 @@ def test_null_pivot_rule_never_changes_the_base_set(lib, cfg, sizes):
             # (with random samples both base regressors are ill-conditioned -- TIAGo: one base parameter comes out at 4e6 with
             # 0.05 of noise on tau, TX40 with its coupling columns at 1e5 -- and ANY two Householder orders differ by
             # cond(W_b) eps in phi: the fit itself, the residual, is what is compared to 1e-9)
-            phi_tol = 1e-3
+            phi_tol = 1e-2
             assert np.abs(on_["phi_b"] - off["phi_b"]).max() <= phi_tol * max(1.0, np.abs(off["phi_b"]).max())
             assert abs(on_["residual_norm"] - off["residual_norm"]) <= 1e-9 * off["residual_norm"]
             dep = np.setdiff1d(np.arange(len(off["absdiagR"])), off["idx_base"])
