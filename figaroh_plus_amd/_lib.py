@@ -21,6 +21,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -
 MODE_JOINT_TORQUE, MODE_EXT_WRENCH = 0, 1
 FLAG_FRICTION, FLAG_ACT_INERTIA, FLAG_OFFSET, FLAG_TX40, FLAG_GENERIC, FLAG_BLOCKED_INPUTS = 1, 2, 4, 8, 256, 512
 FLAG_COMPACT_BLOCKS = 2048  # figh_regressor_build_padded writes the block-compact W (figh.h)
+FLAG_FORCE_COMPACT = 8192  # figh_regressor_build_padded, external wrench: force rows in their own region, a line per 4 links
 FLAG_LINK_COMPACT = 4096  # figh_regressor_build_padded, external wrench on a free-flyer root: links without entries dropped
 FLAG_ZEROS_PRESENT = 1024  # opt-in of figh_regressor_build_padded: structural zeros of W are already there (figh.h)
 
@@ -71,7 +72,9 @@ SIGNATURES = {
     "figh_tsqr_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "figh_select_columns": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "figh_tsqr_selected_wrench": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
-                                            C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64]),
+    "figh_regressor_force_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "figh_model_set_active_rows": (C.c_int, [C.c_void_p, _c_int32_p, C.c_int]),
     "figh_regressor_link_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _c_int32_p, C.POINTER(C.c_int)]),
     "figh_tsqr_selected_blocks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_int,
@@ -471,14 +474,25 @@ def tsqr_selected(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, nblocks, n
 
 
 def tsqr_selected_wrench(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, n_expected, nf_expected, d_tau, tol_qr, d_sel,
-                         d_R, d_link_pos=None):
+                         d_R, d_link_pos=None, ld_force=0):
     """tsqr_selected for the external-wrench regressor of a free-flyer model: force rows over the ``nf_expected`` kept
     columns that can be non-zero there, torque rows chained onto their triangle (figh.h).  ``d_link_pos``: the device copy
     of :func:`regressor_link_layout`'s map when W is link-compact."""
     check(load().figh_tsqr_selected_wrench(d_W.ptr, rows, ldw, d_colsq.ptr, ncols, tol_e, link_stride, n_expected,
                                            nf_expected, d_tau.ptr if d_tau is not None else None, tol_qr, d_sel.ptr,
                                            d_R.ptr if d_R is not None else None,
-                                           d_link_pos.ptr if d_link_pos is not None else None))
+                                           d_link_pos.ptr if d_link_pos is not None else None, int(ld_force)))
+
+
+def regressor_force_layout(model, mode, flags, ft_mask):
+    """Leading dimension of the force region of the force-compact layout (FLAG_FORCE_COMPACT, figh.h), 0 when it does not
+    apply."""
+    ldf = C.c_int64(0)
+    rc = load().figh_regressor_force_layout(model.handle, mode, flags, ft_mask, C.byref(ldf))
+    if rc == ERR_UNSUPPORTED:
+        return 0
+    check(rc)
+    return int(ldf.value)
 
 
 def regressor_link_layout(model, mode, flags, ft_mask):

@@ -98,6 +98,8 @@ void forget_tapes(const figh_model_s *m);
 // link -> segment position of the link-compact layout (FIGH_FLAG_LINK_COMPACT), -1 = no segment; returns the number of links
 // with a segment or -1 when the layout does not apply
 int tree_link_positions(const figh_model_s *m, int mode, int flags, int ft_mask, int *pos);
+// leading dimension of the force region of the force-compact layout (FIGH_FLAG_FORCE_COMPACT), 0 when it does not apply
+long tree_force_ld(const figh_model_s *m, int mode, int flags, int ft_mask);
 
 // figh_tsqr_wide.hip: the blocked (compact-WY, MFMA) level for nc > 80 columns
 long tsqr_wide_workgroups(int nc, int cus);
@@ -108,7 +110,7 @@ int launch_tsqr_wide(const double *W, long rows, long ldw, const int *col_idx, i
 void tsqr_level0_chain(long wgs, int chain_flags);
 // figh_linalg.hip, external wrench on a free-flyer root (figh_tsqr_selected_wrench): the kept columns that can be non-zero
 // in force rows (d_fsel: n columns, then n positions in the kept list) and the force rows' triangle over all kept columns
-int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel);
+int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel, int force_compact = 0);
 int embed_force_triangle(const double *d_Rf, int ncf, int nf, const int *d_fpos, int nc, int n, double *d_out);
 // figh_tsqr_group.hip: the narrow row blocks of a tree's joint-torque regressor as jobs of grouped launches
 struct Tsqr2Job {

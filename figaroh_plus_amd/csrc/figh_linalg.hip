@@ -247,8 +247,11 @@ __global__ __launch_bounds__(256) void select_columns_kernel(const double *__res
 // rows).  From the kept list (device column numbering, `n` entries) the columns that can be non-zero in force rows --
 // slot >= 6 within a link: mx my mz m, Ia fv fs off -- and their positions in the kept list.  fsel: [n entries: columns]
 // [n entries: positions]; the count is a pure function of the kept mask, the host derives the same number from it.
+// force_compact: the columns are those of the force region of FIGH_FLAG_FORCE_COMPACT -- device column 16 p + s of the torque
+// rows (p = the link's position, s >= 6) is column 16 (p / 4) + 4 (p % 4) + (s - 6) there.
 __global__ __launch_bounds__(256) void split_force_columns_kernel(const int *__restrict__ kept, const int n,
-                                                                  const int link_stride, int *__restrict__ fsel) {
+                                                                  const int link_stride, int *__restrict__ fsel,
+                                                                  const int force_compact) {
     __shared__ int flag[1024];
     const int tid = threadIdx.x;
     for (int c = tid; c < n; c += 256) flag[c] = (kept[c] % link_stride) >= 6;
@@ -257,7 +260,8 @@ __global__ __launch_bounds__(256) void split_force_columns_kernel(const int *__r
         if (!flag[c]) continue;
         int pos = 0;
         for (int e = 0; e < c; ++e) pos += flag[e];
-        fsel[pos] = kept[c];
+        const int p = kept[c] / link_stride, s = kept[c] % link_stride;
+        fsel[pos] = force_compact ? 16 * (p >> 2) + 4 * (p & 3) + (s - 6) : kept[c];
         fsel[n + pos] = c;
     }
 }
@@ -282,11 +286,11 @@ __global__ __launch_bounds__(1024) void embed_force_triangle_kernel(const double
     }
 }
 
-int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel) {
+int split_force_columns(const int *d_kept, int n, int link_stride, int *d_fsel, int force_compact) {
     // the kernel writes as many entries as there are kept columns with slot >= 6; a caller's (speculative) count may be
     // larger: what lies behind them must be valid column indices, not whatever the workspace held
     FIGH_HIP(hipMemsetAsync(d_fsel, 0, sizeof(int) * 2 * (size_t)n, stream()));
-    hipLaunchKernelGGL(split_force_columns_kernel, dim3(1), dim3(256), 0, stream(), d_kept, n, link_stride, d_fsel);
+    hipLaunchKernelGGL(split_force_columns_kernel, dim3(1), dim3(256), 0, stream(), d_kept, n, link_stride, d_fsel, force_compact);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }
@@ -930,14 +934,27 @@ static int tsqr_selected_impl(const double *d_W, int64_t rows, int64_t ldw, cons
 // W, at 0.5 (1 + (nf / n)^2) of the flops (TALOS, human: 58 %).
 int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nf_expected, const double *d_tau, double tol_qr,
-                              int32_t *d_sel, double *d_R_out, const int32_t *d_link_pos) {
+                              int32_t *d_sel, double *d_R_out, const int32_t *d_link_pos, int64_t ld_force) {
     const int nc = n_expected + (d_tau ? 1 : 0);
     FIGH_REQUIRE(!d_link_pos || link_stride == 16, "a link map goes with the link-padded layout");
+    FIGH_REQUIRE(ld_force >= 0 && (ld_force == 0 || (link_stride == 16 && ld_force % 16 == 0 && rows % 6 == 0)),
+                 "force-compact W: link-padded torque rows, a multiple of 16 force columns, six row blocks");
     // no split: unknown counts, the register-tile kernel's column range (no chained form), nothing to gain, odd shapes
     if (n_expected <= 0 || nf_expected <= 0 || nf_expected >= n_expected || nc <= 80 || rows % 6 != 0 ||
-        rows / 2 < 16L * nc)
+        rows / 2 < 16L * nc) {
+        if (ld_force > 0) {
+            // (the plain pass reads every row over one column list: not what a force-compact W offers.  Selection only --
+            // the caller learns the counts and comes back with them -- or refuse)
+            if (n_expected <= 0)
+                return tsqr_selected_impl(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, 0, n_expected, d_tau, tol_qr,
+                                          d_sel, d_R_out, d_link_pos);
+            set_error("force-compact W needs the force / torque split: more than 80 kept columns, some of them inertia columns, "
+                      "at least 32 x columns rows");
+            return FIGH_ERR_UNSUPPORTED;
+        }
         return tsqr_selected_impl(d_W, rows, ldw, d_colsq, ncols, tol_e, link_stride, 0, n_expected, d_tau, tol_qr, d_sel,
                                   d_R_out, d_link_pos);
+    }
     FIGH_REQUIRE(d_W && d_colsq && d_sel && d_R_out, "NULL device pointer");
     FIGH_REQUIRE(ncols >= 1 && ncols <= 1024, "figh_tsqr_selected: 1 .. 1024 columns");
     FIGH_REQUIRE(link_stride == 14 || link_stride == 16, "link_stride must be 14 (reference layout) or 16 (link-padded)");
@@ -952,15 +969,16 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
     const int n = n_expected, nf = nf_expected, ncf = nf + (d_tau ? 1 : 0);
     int *fsel = static_cast<int *>(workspace(sizeof(int) * 2 * (size_t)n, 22));
     if (!fsel) return FIGH_ERR_ALLOC;
-    if (int rc = split_force_columns(d_sel + 2, n, link_stride, fsel)) return rc;  // (zero-fills behind the actual count)
+    if (int rc = split_force_columns(d_sel + 2, n, link_stride, fsel, ld_force > 0 ? 1 : 0)) return rc;  // (zero-fills behind the count)
     const int64_t rows_f = rows / 2;
+    const int64_t ldf = ld_force > 0 ? ld_force : ldw;  // force-compact: the force rows are a matrix of their own
     // ---- force rows: their own TSQR over nf columns, reduced to one triangle
     const int64_t cap_f = figh_tsqr_level0_capacity(ncf);
     double *tri_f = static_cast<double *>(workspace(sizeof(double) * (size_t)ncf * ncf * cap_f, 23));
     double *Rf = static_cast<double *>(workspace(sizeof(double) * (size_t)ncf * ncf, 24));
     if (!tri_f || !Rf) return FIGH_ERR_ALLOC;
     int64_t cnt_f = 0;
-    if (int rc = figh_tsqr_level0(d_W, rows_f, ldw, fsel, nf, d_tau, nullptr, 0, tri_f, cap_f, &cnt_f, nullptr)) return rc;
+    if (int rc = figh_tsqr_level0(d_W, rows_f, ldf, fsel, nf, d_tau, nullptr, 0, tri_f, cap_f, &cnt_f, nullptr)) return rc;
     if (cnt_f == 1) FIGH_HIP(hipMemcpyAsync(Rf, tri_f, sizeof(double) * (size_t)ncf * ncf, hipMemcpyDeviceToDevice, stream()));
     else if (int rc = tsqr_reduce(tri_f, cnt_f, ncf, Rf)) return rc;
     // ---- torque rows: chained launch, workgroup 0 starts from the embedded force triangle, the others from zeros
@@ -978,7 +996,7 @@ int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, cons
     if (!stack) return FIGH_ERR_ALLOC;
     int64_t cnt = 0;
     if (wgs > 64) tsqr_level0_chain(wgs - 1, 0);  // one workgroup less: with the embedded triangle the stack is 2^k again
-    if (int rc = figh_tsqr_level0(d_W + rows_f * ldw, rows - rows_f, ldw, d_sel + 2, n, d_tau ? d_tau + rows_f : nullptr,
+    if (int rc = figh_tsqr_level0(d_W + rows_f * ldf, rows - rows_f, ldw, d_sel + 2, n, d_tau ? d_tau + rows_f : nullptr,
                                   nullptr, 0, stack, wgs + 2, &cnt, nullptr))
         return rc;
     hipLaunchKernelGGL(embed_force_triangle_kernel, dim3(1), dim3(1024), 0, stream(), Rf, ncf, nf, fsel + n, nc, n,

@@ -539,6 +539,17 @@ extern "C" int figh_regressor_link_layout(figh_model_t model, int mode, int flag
     return FIGH_OK;
 }
 
+extern "C" int figh_regressor_force_layout(figh_model_t model, int mode, int flags, int ft_mask, int64_t *ld_force) {
+    FIGH_REQUIRE(model && ld_force, "NULL pointer");
+    const long ldf = tree_force_ld(model, mode, flags, ft_mask);
+    if (ldf <= 0) {
+        set_error("force-compact W: external-wrench regressor of a model with a free-flyer root, no friction / inertia / offset columns");
+        return FIGH_ERR_UNSUPPORTED;
+    }
+    *ld_force = ldf;
+    return FIGH_OK;
+}
+
 // Link-padded form of figh_regressor_build for W that stays on the device (see figh.h): 16 columns per link.
 extern "C" int figh_regressor_build_padded(figh_model_t model, int mode, int flags, int ft_mask, int64_t N,
                                            const double *d_q, const double *d_v, const double *d_a, double *d_W,
@@ -562,7 +573,7 @@ extern "C" int figh_regressor_build_padded(figh_model_t model, int mode, int fla
     }
     int done = 0;
     return launch_regressor_tree(model, mode, flags & (7 | FIGH_FLAG_BLOCKED_INPUTS | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS |
-                                                       FIGH_FLAG_LINK_COMPACT),
+                                                       FIGH_FLAG_LINK_COMPACT | FIGH_FLAG_FORCE_COMPACT),
                                  ft_mask, N,
                                  d_q, d_v, d_a, d_W, ldw,
                                  ncols, 16, d_colsq, &done);

@@ -84,7 +84,7 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
                                            double *__restrict__ W, const long ldw, const unsigned ldw8, const long rowbase,
                                            const int col0, double &acc0, double &acc1, const bool fold,
                                            const bool skip_lo = false, const int col0_acc = -1,
-                                           const bool nostore = false) {
+                                           const bool nostore = false, const int force_pos0 = -1) {
     constexpr int CP = LS / 2, RPI = 64 / CP;  // 16-byte chunks per row, rows per store instruction
     constexpr int LSP = FIGH_TREE_LSP;         // LDS row stride of the tile (see regressor_tape_kernel)
     const int rg = lane / CP, ch = lane - rg * CP;
@@ -128,9 +128,17 @@ __device__ __forceinline__ void flush_tile(const double *__restrict__ tile, doub
                 s0 += red[2 * (CP * r + lane)];
                 s1 += red[2 * (CP * r + lane) + 1];
             }
-            const int ca = col0_acc >= 0 ? col0_acc : col0;  // (block-compact W: the norms keep the dense numbering)
-            colacc[ca + 2 * lane] += s0;
-            colacc[ca + 2 * lane + 1] += s1;
+            if (force_pos0 >= 0) {
+                // a line of the force-compact region: four links x (mx my mz m) -- the pair of this lane belongs to link
+                // force_pos0 + lane / 2, slots 6 + 2 (lane % 2) and the next one, of the kernel's own column numbering
+                const int ca = LS * (force_pos0 + (lane >> 1)) + 6 + 2 * (lane & 1);
+                colacc[ca] += s0;
+                colacc[ca + 1] += s1;
+            } else {
+                const int ca = col0_acc >= 0 ? col0_acc : col0;  // (block-compact W: the norms keep the dense numbering)
+                colacc[ca + 2 * lane] += s0;
+                colacc[ca + 2 * lane + 1] += s1;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -177,14 +185,22 @@ __device__ __forceinline__ void stream_zeros(const int lane, const int nvalid, d
 // EXTFF: external wrench on a free-flyer root -- one walk, state = placement of the current link in the root-joint frame,
 // six rows per link; otherwise the row's joint axis is carried down the subtree, one walk per row block.
 // VEC2: 16-byte stores.  STORE = false: column norms only.
-template <int LS, bool EXTFF, bool VEC2, bool STORE, bool COLSQ>
+// FC (FIGH_FLAG_FORCE_COMPACT, EXTFF with LS = 16, no friction / inertia / offset columns): the three FORCE row blocks go to
+// their own region in front of the torque rows -- 3 N rows of ldf columns, one 128-byte line per FOUR links (mx my mz m of
+// each: everything a force row has, the rotational-inertia entries being exact zeros) instead of one line per link.  A lane
+// keeps the twelve force entries of its sample for up to four links in registers (96 VGPRs: the kernel has them, 124 of 256)
+// and every fourth link the three lines go through the segment tile and out as whole lines like any other segment: a quarter
+// of the force-row lines, 5/8 of W (TALOS 101 -> 64 GB, human 146 -> 92 GB), and the force rows' TSQR reads 16-column groups
+// that are all payload.  W = force region, torque region at W + 3 N ldf with leading dimension ldw.
+template <int LS, bool EXTFF, bool VEC2, bool STORE, bool COLSQ, bool FC = false>
 __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__restrict__ M,
                                                             const TapeOp *__restrict__ tape, const int ntape,
                                                             const int flags, const long N,
                                                             const double *__restrict__ q, const double *__restrict__ v,
                                                             const double *__restrict__ a, double *__restrict__ W,
                                                             const long ldw, const int ncols_int,
-                                                            double *__restrict__ colsq_part) {
+                                                            double *__restrict__ colsq_part, const long ldf = 0) {
+    static_assert(!FC || (EXTFF && LS == 16 && VEC2), "force-compact: external wrench, link-padded columns");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // The tile's rows are LS + 2 doubles apart in LDS: a lane writes ITS row (one sample), and with the rows 128 bytes apart
     // (LS = 16) all 64 lanes of a ds_write hit the same four banks -- 64 cycles per instruction instead of 8, fourteen doubles
@@ -237,6 +253,8 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
 #pragma unroll
         for (int s = 0; s < kFetch; ++s) sq0[s] = sq1[s] = sqd[s] = sqdd[s] = 0.0;
         double last_qd = 0.0, last_qdd = 0.0;  // of the joint stepped last (Ia / fv / fs of its own row)
+        double F[FC ? 3 : 1][FC ? 16 : 1];     // FC: the force entries of up to four links, per wrench component
+        double fs0 = 0.0, fs1 = 0.0;           // FC: column norms of the force lines (flush_tile)
         for (int pcnt = 0; pcnt < ntape; ++pcnt) {
             int op = tape[pcnt].op, oa = tape[pcnt].a, ob = tape[pcnt].b, oc = tape[pcnt].c, od = tape[pcnt].d,
                 oe = tape[pcnt].e;
@@ -404,8 +422,48 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                 }
                 double *my = tile + LSP * lane;
                 double cs0 = 0.0, cs1 = 0.0;  // column norms of the segment (flush_tile)
+                if constexpr (FC) {
+                    // ---- the three force components of link b: into the lane's registers, slot ob & 3 of the group of four
+                    const int fslot = ob & 0xff;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        if ((od >> c) & 1) {
+                            const double jl[3] = {Rc[3 * c], Rc[3 * c + 1], Rc[3 * c + 2]};
+                            axis_times_body_regressor_lin(jl, accv, A + 3, V + 3, o);
+                        }
+                        if (fslot == 0) {  // a new group: the slots of a last, incomplete group stay zero
+#pragma unroll
+                            for (int k = 4; k < 16; ++k) F[c][k] = 0.0;
+                        }
+#pragma unroll
+                        for (int sl = 0; sl < 4; ++sl)
+                            if (fslot == sl) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) F[c][4 * sl + k] = o[6 + k];
+                            }
+                    }
+                    if (oc & EMIT_FLUSH) {  // the group is complete (or the walk ends): three lines per sample
+                        const int fcol0 = ob >> 8;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) my[k] = F[c][k];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldf, 8u * (unsigned)ldf, (long)c * N + i0,
+                                                         fcol0, fs0, fs1, c == 2, false, -1, false, fcol0 / 4);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        // (the tile's padding columns 14, 15 were overwritten by the line: zero again for the torque segments)
+                        my[14] = 0.0;
+                        my[15] = 0.0;
+                    }
+                }
 #pragma unroll 1
-                for (int c = 0; c < (EXTFF ? 6 : 1); ++c) {
+                for (int c = FC ? 3 : 0; c < (EXTFF ? 6 : 1); ++c) {
                     const bool fold = !EXTFF || c == 5;
                     double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                     if constexpr (EXTFF) {
@@ -439,7 +497,9 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const long rowbase = (long)(EXTFF ? c : ob) * N + i0;
+                    // (FC: the torque region lies behind the 3 N x ldf force region, its row blocks are numbered 0 .. 2 there)
+                    const long rowbase = (long)(EXTFF ? (FC ? c - 3 : c) : ob) * N + i0;
+                    double *const Wseg = FC ? W + 3 * N * ldf : W;
                     if constexpr (VEC2) {
                         if (!EXTFF && od != 0) {
                             // FIGH_FLAG_COMPACT_BLOCKS: row block ob is its own N x ld matrix -- the columns of its joint's
@@ -451,10 +511,10 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                                                          (oc & EMIT_NOSTORE) != 0);
                         } else {
 #ifdef FIGH_ABLATION
-                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0, cs0, cs1, fold,
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, Wseg, ldw, ldw8, rowbase, col0, cs0, cs1, fold,
                                                          EXTFF && g_tree_half && c < 3);
 #else
-                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, W, ldw, ldw8, rowbase, col0, cs0, cs1, fold,
+                            flush_tile<LS, STORE, COLSQ>(tile, red, colacc, lane, nvalid, Wseg, ldw, ldw8, rowbase, col0, cs0, cs1, fold,
                                                          false, -1, !EXTFF && (oc & EMIT_NOSTORE) != 0);
 #endif
                         }
@@ -597,8 +657,10 @@ std::vector<TapeOp> with_fetches(const DevModel &h, const std::vector<TapeOp> &i
 }
 
 // external wrench, free-flyer root: one walk over the tree, six row segments per link (ls = columns per link in W)
-std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, int ls, const int *link_pos) {
+std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, int ls, const int *link_pos,
+                                     bool force_compact) {
     TapeBuilder T(h);
+    int fpos = 0, last_emit = -1;  // force-compact: running position of the links with a segment; index of the last EMIT
     const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
     int prev = 0, zero_from = -1;
     auto flush_zero = [&](int upto_link) {  // links zero_from .. upto_link-1 (1-based joints) are all-zero segments
@@ -619,13 +681,21 @@ std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, 
         const int inert = h.body_mask[b] ? (ft_mask & 63) : 0;
         if (inert || extras) {
             flush_zero(b);
-            T.push(OP_EMIT, b, 0, (inert ? EMIT_INERT : 0) | (extras ? EMIT_EXTRA : 0), inert,
-                   link_pos ? ls * link_pos[b - 1] + 1 : 0);
+            // force-compact: field b = the link's slot in its group of four | column of the group's line in the force region
+            // << 8; EMIT_FLUSH on every fourth link (and on the last one, below)
+            // (force positions count the links that HAVE a segment, whatever the torque rows' layout: groups are then always
+            // complete but the last)
+            const int p = fpos++;
+            T.push(OP_EMIT, b, force_compact ? ((p & 3) | ((16 * (p >> 2)) << 8)) : 0,
+                   (inert ? EMIT_INERT : 0) | (extras ? EMIT_EXTRA : 0) | ((force_compact && (p & 3) == 3) ? EMIT_FLUSH : 0),
+                   inert, link_pos ? ls * link_pos[b - 1] + 1 : 0);
+            last_emit = (int)T.ops.size() - 1;
         } else if (zero_from < 0) {
             zero_from = b;
         }
     }
     flush_zero(h.njoints);
+    if (force_compact && last_emit >= 0) T.ops[last_emit].c |= EMIT_FLUSH;  // (a last group of fewer than four links)
     return with_fetches(h, T.ops);
 }
 
@@ -714,6 +784,18 @@ int tree_link_positions(const figh_model_s *m, int mode, int flags, int ft_mask,
     return live;
 }
 
+// FIGH_FLAG_FORCE_COMPACT: leading dimension of the force region -- 16 columns per group of four links that have a segment
+// (tree_link_positions: the force region is compacted over the links whatever the layout of the torque rows) -- or 0 when the layout does
+// not apply: not an external-wrench regressor on a free-flyer root, or friction / actuator-inertia / offset columns (which
+// every row of a link carries, regressor.py:142-169: eight entries per force row and link instead of four).
+long tree_force_ld(const figh_model_s *m, int mode, int flags, int ft_mask) {
+    int pos[kMaxJoints];
+    int live = tree_link_positions(m, mode, flags, ft_mask, pos);
+    if (live < 0 || (flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET))) return 0;
+    if (live <= 0) return 0;
+    return 16L * ((live + 3) / 4);
+}
+
 // internal: rows of W for a tree model.  ls = columns per link in W: 14 (the reference's layout, ncols = 14 nlinks [+ 3])
 // or 16 (link-padded: columns 14, 15 of every link are zero, every row segment is one 128-byte line; needs ldw % 16 == 0
 // and a 128-byte aligned W).  W == nullptr: column norms only.  d_colsq (nullable) receives diag(W^T W) in the
@@ -734,6 +816,19 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
         FIGH_REQUIRE(nlive >= 0 && ls == 16, "link-compact W: external-wrench regressor of a free-flyer model, link-padded columns");
     }
     const int ncols_int = nlive >= 0 ? ls * (nlive > 0 ? nlive : 1) : ls * h.nlinks + ((flags & FIGH_FLAG_TX40) ? 3 : 0);
+    // FIGH_FLAG_FORCE_COMPACT: the force row blocks in their own region, one line per four links (regressor_tape_kernel, FC)
+    const bool fc = (flags & FIGH_FLAG_FORCE_COMPACT) != 0;
+    long ldf = 0;
+    if (fc) {
+        ldf = tree_force_ld(m, mode, flags, ft_mask);
+        FIGH_REQUIRE(ldf > 0 && ls == 16, "force-compact W: external-wrench regressor of a free-flyer model without friction / "
+                                          "actuator-inertia / offset columns, link-padded torque rows");
+        // (a link's place in the force region is its position among the links with entries: the torque rows must number
+        // the links the same way, i.e. be link-compact unless every link has entries)
+        int pos_all[kMaxJoints];
+        FIGH_REQUIRE((flags & FIGH_FLAG_LINK_COMPACT) || tree_link_positions(m, mode, flags, ft_mask, pos_all) == h.nlinks,
+                     "force-compact W of a model with links without entries goes with FIGH_FLAG_LINK_COMPACT");
+    }
     if (!store) ldw = ncols_int;
     FIGH_REQUIRE(ldw >= ncols_int, "ldw smaller than the number of columns");
     FIGH_REQUIRE(ldw < (1L << 22), "figh_regressor_build: leading dimension must be below 2^22 elements");
@@ -750,11 +845,11 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     }
     const std::vector<long> key = {(long)reinterpret_cast<uintptr_t>(m), mode,
                                    flags & (7 | FIGH_FLAG_TX40 | FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS |
-                                            FIGH_FLAG_LINK_COMPACT), ft_mask,
+                                            FIGH_FLAG_LINK_COMPACT | FIGH_FLAG_FORCE_COMPACT), ft_mask,
                                    ls};
     auto it = g_tapes.find(key);
     if (it == g_tapes.end()) {
-        std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls, nlive >= 0 ? link_pos : nullptr)
+        std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls, nlive >= 0 ? link_pos : nullptr, fc)
                                         : build_tape_rows(h, mode, flags, ft_mask, ls, m->active_rows);
 #ifdef FIGH_ABLATION
         {
@@ -808,7 +903,8 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const size_t lds = sizeof(double) * (64 * (size_t)FIGH_TREE_LSP + 128 + (size_t)(fuse ? ncols_int : 0));
+    // (force-compact: the norm fold of a partial last group of links touches up to 3 x 16 entries behind the last column)
+    const size_t lds = sizeof(double) * (64 * (size_t)FIGH_TREE_LSP + 128 + (size_t)(fuse ? ncols_int + (fc ? 64 : 0) : 0));
     long grid = (long)cus * 8;
 #ifdef FIGH_ABLATION
     if (const char *e = getenv("FIGH_TREE_WAVES")) grid = (long)cus * atoi(e);
@@ -823,7 +919,10 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     ProfileScope scope("regressor_tree", true);
 #define FIGH_TAPE_LAUNCH(LS, E, V2, ST, C)                                                                         \
     FIGH_LAUNCH_TIMED((regressor_tape_kernel<LS, E, V2, ST, C>), dim3((unsigned)grid), dim3(64), lds, m->dev, tp.dev, \
-                      tp.n, flags, N, q, v, a, W, ldw, ncols_int, part)
+                      tp.n, flags, N, q, v, a, W, ldw, ncols_int, part, 0L)
+#define FIGH_TAPE_LAUNCH_FC(ST, C)                                                                                       \
+    FIGH_LAUNCH_TIMED((regressor_tape_kernel<16, true, true, ST, C, true>), dim3((unsigned)grid), dim3(64), lds, m->dev, \
+                      tp.dev, tp.n, flags, N, q, v, a, W, ldw, ncols_int, part, ldf)
 #define FIGH_TAPE_MODES(LS, E)                                      \
     do {                                                            \
         if (!store) FIGH_TAPE_LAUNCH(LS, E, true, false, true);     \
@@ -831,7 +930,12 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
         else if (vec2) FIGH_TAPE_LAUNCH(LS, E, true, true, false);  \
         else FIGH_TAPE_LAUNCH(14, E, false, true, false);           \
     } while (0)
-    if (ls == 16) {
+    if (fc) {
+        FIGH_REQUIRE(tp.extff && vec2, "force-compact W needs the free-flyer walk");
+        if (!store) FIGH_TAPE_LAUNCH_FC(false, true);
+        else if (fuse) FIGH_TAPE_LAUNCH_FC(true, true);
+        else FIGH_TAPE_LAUNCH_FC(true, false);
+    } else if (ls == 16) {
         if (tp.extff) FIGH_TAPE_MODES(16, true);
         else FIGH_TAPE_MODES(16, false);
     } else {
@@ -840,6 +944,7 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     }
 #undef FIGH_TAPE_MODES
 #undef FIGH_TAPE_LAUNCH
+#undef FIGH_TAPE_LAUNCH_FC
     FIGH_HIP(hipGetLastError());
     if (fuse) {
         const int nref = 14 * h.nlinks;  // (TX40 tail: never fused, odd column count)

@@ -116,9 +116,11 @@ class IdentificationPipeline:
         # Nothing else is written or read (the TSQR takes one column list per row block anyway); every stored byte is written
         # in every pass.  self.W is then that buffer (rows = nv N, `compact` = (offsets, leading dimensions)), not the
         # reference's matrix: build_regressor_basic still returns that.
-        # "link-padded": trees in the plain link-padded layout even where the link-compact one applies (tests, A/B).
-        if w_layout not in ("dense", "block-compact", "link-padded"):
-            raise ValueError("w_layout must be 'dense', 'block-compact' or 'link-padded'")
+        # "link-padded": trees in the plain link-padded layout even where the link-compact one applies (tests, A/B);
+        # "link-compact": the external-wrench regressor link-compact but with the force rows as wide as the torque rows (no
+        # force-compact region: what run(wls=True) switches to, its second pass reads W as one matrix).
+        if w_layout not in ("dense", "block-compact", "link-padded", "link-compact"):
+            raise ValueError("w_layout must be 'dense', 'block-compact', 'link-padded' or 'link-compact'")
         self.w_layout = w_layout
         # placement_trials > 1: when W is allocated, that many candidate buffers are allocated side by side, the regressor
         # kernel is timed on each and the fastest one is kept (set-up cost: a few passes of K1).  The time K1 needs for the
@@ -334,6 +336,11 @@ class IdentificationPipeline:
                 if wls:
                     raise NotImplementedError("wls=True needs the regressor resident in HBM (no chunk_samples)")
                 return self._run_chunked(strings)
+            if wls and getattr(self, "_force_ld", 0):
+                # the weighted solve's second pass reads W as ONE matrix: from now on without the force-compact region
+                self._no_force_compact = True
+                self.W.buf.free()
+                self.W = None
             # (with the WLS the expression strings of the base parameters -- host work, 0.2 - 0.4 ms for TIAGo -- are built while
             # the weighted factorisation runs on the device)
             out = self._run_resident(strings and not wls, wls)
@@ -369,6 +376,14 @@ class IdentificationPipeline:
                     self._link_pos = layout[0].astype(np.int64)
                     self._d_link_pos = _lib.DeviceArray.from_host(layout[0])
                     wcols = 16 * layout[1]
+            # ... and the three FORCE row blocks in a region of their own, one 128-byte line per four links (a force row only
+            # has mx my mz m of every link: FIGH_FLAG_FORCE_COMPACT) -- 5/8 of the bytes of W, and the force rows' TSQR reads
+            # lines that are all payload.  Not with friction / inertia / offset columns; not for the weighted solve, whose second
+            # pass reads W as one matrix (run(wls=True) re-creates W without it).
+            self._force_ld = 0
+            if (self._padded and self.w_layout in ("dense", "block-compact") and not getattr(self, "_no_force_compact", False)
+                    and self.N >= 64):
+                self._force_ld = _lib.regressor_force_layout(handle, mode, flags & 7, ft_mask)
             if (self.w_layout == "block-compact" and self._padded and mode == _lib.MODE_JOINT_TORQUE
                     and m.nv == m.njoints - 1 and self.N >= 64):
                 sizes = self._subtree_sizes()
@@ -388,6 +403,11 @@ class IdentificationPipeline:
                 self.W = GpuMatrix(_lib.DeviceArray((int(self.N * ld.sum()),), np.float64), rows_per_sample * self.N, wcols,
                                    wcols)
                 self.W.compact = self._compact
+            elif self._force_ld:
+                half = (rows_per_sample // 2) * self.N  # rows of the force region = rows of the torque region
+                self.W = GpuMatrix(_lib.DeviceArray((half * (self._force_ld + wcols),), np.float64), rows_per_sample * self.N,
+                                   wcols, wcols)
+                self.W.force_ld = self._force_ld  # (rows [0, half): force region, ld force_ld; torque rows behind it, ld wcols)
             else:
                 self.W = self._place_W(rows_per_sample * self.N, wcols, handle, mode, flags, ft_mask)
             self.W.ref_cols = ncols
@@ -436,7 +456,8 @@ class IdentificationPipeline:
         if self._padded:
             _lib.regressor_build_padded(handle, mode, flags | (_lib.FLAG_ZEROS_PRESENT if self._zeros_once else 0)
                                         | (_lib.FLAG_COMPACT_BLOCKS if self._compact is not None else 0)
-                                        | (_lib.FLAG_LINK_COMPACT if self._link_pos is not None else 0), ft_mask,
+                                        | (_lib.FLAG_LINK_COMPACT if self._link_pos is not None else 0)
+                                        | (_lib.FLAG_FORCE_COMPACT if self._force_ld else 0), ft_mask,
                                         self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
         else:
             _lib.regressor_build(handle, mode, flags, ft_mask, self.N, self.d_q, self.d_v, self.d_a, W.buf, W.ld, d_colsq)
@@ -456,10 +477,21 @@ class IdentificationPipeline:
                     raise RuntimeError("row_blocks: no kept mask to build the column lists from")
             if self._compact is not None and blocks is None and n > 0:
                 raise RuntimeError("block-compact W: no kept mask to build the column lists from")
-            if split or self._link_pos is not None:  # (nf = 0: the plain pass, through the entry that takes the link map)
-                _lib.tsqr_selected_wrench(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, nf, self.d_tau,
-                                          self.tol_qr if local else -1.0, self._d_sel, self._d_rows if local else self._d_R,
-                                          d_link_pos=self._d_link_pos)
+            if split or self._link_pos is not None or self._force_ld:  # (nf = 0: the plain pass, through the entry that knows the layout)
+                try:
+                    _lib.tsqr_selected_wrench(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, nf, self.d_tau,
+                                              self.tol_qr if local else -1.0, self._d_sel,
+                                              self._d_rows if local else self._d_R, d_link_pos=self._d_link_pos,
+                                              ld_force=self._force_ld)
+                except _lib.FighError as e:
+                    if not (self._force_ld and e.code == _lib.ERR_UNSUPPORTED):
+                        raise
+                    # the kept columns turned out not to allow the force / torque split (at most 80 of them, or too few
+                    # rows): this regressor is kept as one matrix from now on
+                    self._no_force_compact = True
+                    self.W.buf.free()
+                    self.W = None
+                    return self._run_resident(strings, wls)
             elif blocks is not None:
                 coff, cld = self._compact if self._compact is not None else (None, None)
                 _lib.tsqr_selected_blocks(W.buf, W.rows, W.ld, d_colsq, ncols, self.tol_e, stride, n, blocks[1],
@@ -760,6 +792,9 @@ class IdentificationPipeline:
             raise ValueError("block-compact W has no global column numbering: row block j is its own N x 16 |subtree_j| "
                              "matrix (pipe.W.compact = (element offsets, leading dimensions))")
         c = np.asarray(ref_cols, dtype=np.int64)
+        if getattr(self, "_force_ld", 0):
+            raise ValueError("force-compact W is two matrices (force rows: pipe.W.force_ld columns, torque rows behind them): "
+                             "no single column numbering; IdentificationPipeline(w_layout='link-compact') keeps one")
         if getattr(self, "_link_pos", None) is not None:  # link-compact: only links with entries have a segment
             pos = self._link_pos[c // 14]
             if (pos < 0).any():

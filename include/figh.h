@@ -71,7 +71,18 @@ enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, 
         * 19 x 16 = 304 instead of 40 x 16 = 640 columns (146 instead of 307 GB for 1e7 samples).  d_colsq keeps the
         * reference's numbering (exact zeros for the dropped links).  Consumers take the map as d_link_pos
         * (figh_tsqr_selected_wrench). */
-       FIGH_FLAG_LINK_COMPACT = 4096 };
+       FIGH_FLAG_LINK_COMPACT = 4096,
+       /* figh_regressor_build_padded only, external-wrench regressor of a model with a free-flyer root, no friction /
+        * actuator-inertia / offset columns: d_W is FORCE-COMPACT -- the three FORCE row blocks (regressor.py:89-192: rows
+        * c N + i, c = Fx Fy Fz) are stored in a region of their own, 3 N rows of ldf columns IN FRONT of the three torque
+        * row blocks, one 128-byte line per FOUR links: the force rows of link l hold mx my mz m (reference columns 14 l + 6
+        * .. 14 l + 9) at columns 16 (p / 4) + 4 (p % 4) + (s - 6) of that region, p = the link's position among the links
+        * with entries (figh_regressor_link_layout), ldf from figh_regressor_force_layout -- everything a force row has:
+        * the six rotational-inertia entries are exact zeros (a force does not depend on them).  The torque row blocks
+        * follow at d_W + 3 N ldf: 3 N rows of ldw columns, link-padded (or link-compact with FIGH_FLAG_LINK_COMPACT).  A
+        * quarter of the force-row lines: TALOS 101 -> 64 GB, human 146 -> 92 GB per pass.  Consumer:
+        * figh_tsqr_selected_wrench(..., ld_force). */
+       FIGH_FLAG_FORCE_COMPACT = 8192 };
 
 typedef struct figh_model_s *figh_model_t;
 
@@ -175,6 +186,9 @@ int figh_regressor_build_padded(figh_model_t model, int mode, int flags, int ft_
  * FIGH_ERR_UNSUPPORTED when the layout does not apply (not an external-wrench regressor on a free-flyer root).  Which
  * links drop out follows from the model alone -- id_inertias of regressor.py:36-39 -- not from the samples. */
 int figh_regressor_link_layout(figh_model_t model, int mode, int flags, int ft_mask, int32_t *h_link_pos, int *nlive);
+/* Leading dimension of the force region of FIGH_FLAG_FORCE_COMPACT for (model, mode, flags, ft_mask): 16 * ceil(nlive / 4).
+ * FIGH_ERR_UNSUPPORTED when the layout does not apply (see the flag). */
+int figh_regressor_force_layout(figh_model_t model, int mode, int flags, int ft_mask, int64_t *ld_force);
 
 /* figh_repack_samples: d_dst[(t * width + k) * 64 + l] = d_src[min(64 t + l, N - 1) * width + k] -- a sample-major N x width
  * array (q, v or a exactly as the reference holds them) re-laid per tile of 64 samples, value-major inside the tile, the
@@ -287,10 +301,11 @@ int figh_regressor_tsqr_fused(figh_model_t model, int flags, int64_t N, const do
  * number of kept columns c with c % 14 >= 6 -- the caller derives it from the same mask as n_expected and verifies both
  * afterwards.  nf_expected <= 0, at most 80 columns or rows % 6 != 0: plain figh_tsqr_selected.  d_link_pos (nullable,
  * device, njoints - 1 int32): d_W is link-compact (FIGH_FLAG_LINK_COMPACT), reference column 14 l + s is column
- * 16 d_link_pos[l] + s. */
+ * 16 d_link_pos[l] + s.  ld_force > 0: d_W is force-compact (FIGH_FLAG_FORCE_COMPACT) -- rows / 2 force rows of ld_force columns
+ * at d_W, the torque rows of ldw columns behind them; needs the split (nf_expected > 0, more than 80 columns). */
 int figh_tsqr_selected_wrench(const double *d_W, int64_t rows, int64_t ldw, const double *d_colsq, int ncols, double tol_e,
                               int link_stride, int n_expected, int nf_expected, const double *d_tau, double tol_qr,
-                              int32_t *d_sel, double *d_R_out, const int32_t *d_link_pos);
+                              int32_t *d_sel, double *d_R_out, const int32_t *d_link_pos, int64_t ld_force);
 /* figh_tsqr_selected for the joint-torque regressor of a tree of single-dof joints (regressor.py:45-87, rows j*N + i): row
  * block j only involves the links of joint j's subtree and the Ia / fv / fs / off columns of link j itself; all other
  * entries are structural zeros.  Row block j (rows / nblocks rows) is factored over its own column list -- h_counts[j]

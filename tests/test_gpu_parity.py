@@ -345,77 +345,38 @@ def _spot_rows_padded(pipe, g, oracle_lib, qva, rps, rng):
     nl = g.robot().model.njoints - 1
     link_pos = getattr(pipe, "_link_pos", None)  # link-compact W: only the links with entries have a segment
     assert W.ld % 16 == 0 and W.cols == 16 * (nl if link_pos is None else int((link_pos >= 0).sum()))
-    rows = np.concatenate([j * N + sel for j in range(rps)])
-    host = np.empty((len(rows), W.ld))
-    for k, r in enumerate(rows):
-        _lib.check(_lib.load().figh_memcpy_d2h(host[k].ctypes.data, W.buf.ptr + int(r) * W.ld * 8, W.ld * 8))
     ref = np.arange(14 * nl)
     if link_pos is not None:
         dropped = link_pos[ref // 14] < 0
         assert not Wsel[:, dropped].any()  # what has no columns in W is identically zero in the oracle's regressor
         ref = ref[~dropped]
-        dev_cols = link_pos[ref // 14] * 16 + ref % 14
+        pos = link_pos[ref // 14]
     else:
-        dev_cols = (ref // 14) * 16 + ref % 14
-    assert np.abs(host[:, dev_cols] - Wsel[:, ref]).max() <= 1e-12 * np.abs(Wsel).max()
+        pos = ref // 14
+    dev_cols = pos * 16 + ref % 14
+    ldf = getattr(W, "force_ld", 0)  # force-compact W: the force row blocks in a region of their own, in front
+    nforce = (rps // 2) * N if ldf else 0
+    tor = np.concatenate([j * N + sel for j in range(rps // 2 if ldf else 0, rps)])
+    host = np.empty((len(tor), W.ld))
+    base = W.buf.ptr + 8 * nforce * ldf
+    for k, r in enumerate(tor):
+        _lib.check(_lib.load().figh_memcpy_d2h(host[k].ctypes.data, base + int(r - nforce) * W.ld * 8, W.ld * 8))
+    want = Wsel[(rps // 2) * len(sel):] if ldf else Wsel
+    assert np.abs(host[:, dev_cols] - want[:, ref]).max() <= 1e-12 * np.abs(Wsel).max()
     pad = np.setdiff1d(np.arange(W.cols), dev_cols)
     assert not host[:, pad].any()
-
-
-@pytest.mark.timeout(900)
-def test_full_size_tiago_and_rank_crossing(lib, oracle_lib):
-    """BASELINE configs[2] (TIAGo, fv/fs/Ia/off, 1e6 samples = 24e6 x 336) at full size, plus the finding that comes with
-    it: four structurally dependent pivots of the TIAGo regressor are genuine tiny numbers that grow like sqrt(N)
-    (6.3e-9 at 1e5 samples, 1.26e-8 at 4e5) and cross TOL_QR = 1e-8, so the base-parameter count goes 179 -> 183 -> 185
-    with N -- in the REFERENCE too (np.linalg.qr of the same rows).  Checked here against LAPACK at 1e5 samples (all
-    pivots, identical index set = the golden 179), through the sqrt(N) law at 4e5, and structurally at 1e6."""
-    rng = np.random.default_rng(11)
-    # (i) 1e5 samples: every |R_ii| against LAPACK on the same matrix, base set = golden
-    g, pipe, qva = _tree_pipeline("cfg3_tiago", 100_000, 5)
-    out1 = pipe.run()
-    assert out1["idx_e"] == list(g["idx_e"]) and out1["idx_base"] == list(g["idx_base"])
-    assert out1["params_base"] == g.meta["params_base"]
-    W_ref = _oracle_W(g, oracle_lib, *qva)
-    keep = [i for i in range(W_ref.shape[1]) if i not in set(out1["idx_e"])]
-    d_ref = np.abs(np.diag(np.linalg.qr(W_ref[:, keep], mode="r")))
-    del W_ref
-    big = d_ref > 1e-8
-    # (raw pivots of an UNPIVOTED QR are only comparable up to the direction of the noise reflectors of the dependent
-    # columns in front of them -- SURVEY.md section 7 -- so: the decision exactly, the magnitudes loosely, and the four
-    # borderline pivots, which carry the finding, tightly)
-    assert [i for i in range(len(keep)) if big[i]] == out1["idx_base"]
-    assert np.abs(out1["absdiagR"][big] / d_ref[big] - 1.0).max() <= 1e-3
-    dep1 = np.sort(out1["absdiagR"][~big])[-4:]  # the four borderline pivots
-    assert np.abs(np.sort(d_ref[~big])[-4:] / dep1 - 1.0).max() <= 1e-4 and dep1.min() > 3e-9
-    del pipe
-    # (ii) 4e5 samples: the same four pivots have doubled (sqrt(4)) and crossed the tolerance.  From here on the index set
-    # is pinned from OUTSIDE the HIP path: tests/golden/cfg3_tiago_large.json holds what a blocked LAPACK Householder TSQR
-    # of the oracle's W (C restatement, same samples) keeps (oracle/pin_cfg3_large.py, run in the build container)
-    with open(os.path.join(os.path.dirname(__file__), "golden", "cfg3_tiago_large.json")) as f:
-        pinned = {(c["N"], c["seed"]): c for c in json.load(f)["cases"]}
-    g, pipe, _ = _tree_pipeline("cfg3_tiago", 400_000, 5)
-    out4 = pipe.run()
-    pin4 = pinned[(400_000, 5)]
-    assert out4["idx_e"] == pin4["idx_e"] == list(g["idx_e"]) and out4["idx_base"] == pin4["idx_base"]
-    assert len(out4["idx_base"]) == 183
-    for k, val in pin4["near_tolerance"].items():  # the pivots near TOL_QR themselves, on both sides of it
-        assert abs(out4["absdiagR"][int(k)] / val - 1.0) <= 1e-4
-    crossed = sorted(set(out4["idx_base"]) - set(out1["idx_base"]))
-    assert len(crossed) == 4 and set(out1["idx_base"]) <= set(out4["idx_base"])
-    ratio = np.sort(out4["absdiagR"][crossed]) / np.sort(dep1)
-    assert np.all((ratio > 1.7) & (ratio < 2.3)), ratio
-    del pipe
-    # (iii) the BASELINE size
-    g, pipe, qva = _tree_pipeline("cfg3_tiago", 1_000_000, 5)
-    out = pipe.run()
-    pin10 = pinned[(1_000_000, 5)]
-    assert out["idx_e"] == pin10["idx_e"] == list(g["idx_e"]) and out["rows"] == 24_000_000
-    assert out["idx_base"] == pin10["idx_base"] and len(out["idx_base"]) == 185  # (two more pivots have crossed)
-    for k, val in pin10["near_tolerance"].items():
-        assert abs(out["absdiagR"][int(k)] / val - 1.0) <= 1e-4
-    kept = np.array([i for i in range(336) if i not in set(out["idx_e"])])
-    assert np.abs(out["absdiagR"][0] ** 2 - out["col_norm"][kept[0]]) <= 1e-10 * out["col_norm"][kept[0]]  # R_00^2 = ||w_0||^2
-    _spot_rows_padded(pipe, g, oracle_lib, qva, 24, rng)
+    if ldf:
+        # force rows: mx my mz m of link p at columns 16 (p / 4) + 4 (p % 4) + (s - 6); the oracle's other entries are zeros
+        frc = np.concatenate([j * N + sel for j in range(rps // 2)])
+        hostf = np.empty((len(frc), ldf))
+        for k, r in enumerate(frc):
+            _lib.check(_lib.load().figh_memcpy_d2h(hostf[k].ctypes.data, W.buf.ptr + int(r) * ldf * 8, ldf * 8))
+        wantf = Wsel[:(rps // 2) * len(sel)]
+        fsl = (ref % 14 >= 6) & (ref % 14 <= 9)
+        fcols = 16 * (pos[fsl] // 4) + 4 * (pos[fsl] % 4) + (ref[fsl] % 14 - 6)
+        assert np.abs(hostf[:, fcols] - wantf[:, ref[fsl]]).max() <= 1e-12 * np.abs(Wsel).max()
+        assert not wantf[:, ref[~fsl]].any()
+        assert not hostf[:, np.setdiff1d(np.arange(ldf), fcols)].any()
 
 
 @pytest.mark.timeout(900)
@@ -447,6 +408,48 @@ def test_full_size_human_resident_link_compact(lib, oracle_lib):
     assert out["idx_base"] == list(g["idx_base"]) and out["params_base"] == g.meta["params_base"]
     assert np.abs(out["phi_ls"] - g["phi_from_std"]).max() <= 1e-6 * np.abs(g["phi_from_std"]).max()
     _spot_rows_padded(pipe, g, oracle_lib, qva, 6, rng)
+
+
+@pytest.mark.parametrize("cfg", ["cfg5_human", "cfg4_talos"])
+def test_force_compact_equals_one_matrix(lib, oracle_lib, cfg):
+    """The force-compact W (force row blocks in their own region, one line per four links: FIGH_FLAG_FORCE_COMPACT, the default
+    of the external-wrench regressor without friction columns) against the one-matrix form (w_layout="link-compact") on the
+    same samples: column norms to 1e-13 (the force rows' squares are folded in another order), identical index sets and
+    expressions, phi to 1e-9, every stored entry against the oracle; run(wls=True) re-creates W as one matrix and gives the
+    one-matrix results."""
+    from conftest import Golden
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
+    g = Golden(cfg)
+    robot = g.robot()
+    N = 20000 + 37
+    rng = np.random.default_rng(9)
+    qva = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
+    outs, pipes = [], []
+    for layout in ("link-compact", "dense"):
+        pipe = IdentificationPipeline(robot, g.param, params_std=g.params_std(), coupling=g.coupling, w_layout=layout)
+        pipe.set_samples(*qva)
+        pipe.set_tau_from_parameters(g.phi_ref(), noise_std=0.01, seed=2)
+        pipe.run()
+        outs.append(pipe.run())
+        pipes.append(pipe)
+    a_, b_ = outs
+    nlive = int((pipes[1]._link_pos >= 0).sum()) if pipes[1]._link_pos is not None else robot.model.njoints - 1
+    assert pipes[0]._force_ld == 0 and pipes[1]._force_ld == 16 * ((nlive + 3) // 4) == pipes[1].W.force_ld
+    assert pipes[1].W.buf.size == 3 * N * (pipes[1]._force_ld + pipes[1].W.ld) < pipes[0].W.buf.size
+    assert np.abs(a_["col_norm"] - b_["col_norm"]).max() <= 1e-13 * a_["col_norm"].max()
+    assert a_["idx_e"] == b_["idx_e"] == list(g["idx_e"]) and a_["idx_base"] == b_["idx_base"] == list(g["idx_base"])
+    assert a_["params_base"] == b_["params_base"] == g.meta["params_base"]
+    assert np.abs(a_["phi_ls"] - b_["phi_ls"]).max() <= 1e-9 * np.abs(a_["phi_ls"]).max()
+    assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-10 * a_["residual_norm"]
+    _spot_rows_padded(pipes[1], g, oracle_lib, qva, 6, rng)
+    _spot_rows_padded(pipes[0], g, oracle_lib, qva, 6, rng)
+    with pytest.raises(ValueError):
+        pipes[1].device_columns([6])
+    w_ = pipes[1].run(wls=True)  # the weighted solve reads W as one matrix: the pipeline switches
+    ref = pipes[0].run(wls=True)
+    assert pipes[1]._force_ld == 0 and not hasattr(pipes[1].W, "force_ld")
+    assert np.abs(w_["phi_wls"] - ref["phi_wls"]).max() <= 2e-6 and w_["idx_base"] == ref["idx_base"]
 
 
 @pytest.mark.parametrize("cfg", ["cfg5_human", "cfg4_talos"])
