@@ -384,9 +384,10 @@ def main():
             roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
                                   "dense_bytes_per_sample": bytes_per_sample,
                                   "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
-        if getattr(pipe, "_link_pos", None) is not None:
-            # link-compact W: links without entries (massless bodies) have no columns; same accounting as above
-            stored = 8 * (m.nq + 2 * m.nv) + 8 * rows_per_sample * 16.0 * int((pipe._link_pos >= 0).sum())
+        if getattr(pipe, "_link_pos", None) is not None or getattr(pipe, "_force_ld", 0):
+            # link-compact / force-compact W: links without entries (massless bodies) have no columns, the force rows one
+            # line per four links; same accounting as above
+            stored = 8 * (m.nq + 2 * m.nv) + 8.0 * pipe.W.buf.size / pipe.N
             roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
                                   "dense_bytes_per_sample": bytes_per_sample,
                                   "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
@@ -533,9 +534,14 @@ def main():
                 "w_layout": ("block-compact: row block j = N x 16 |subtree_j| (%.1f GB instead of %.1f GB)"
                              % (8e-9 * pipe.N * float(pipe._compact[1].sum()), 8e-9 * pipe.W.rows * pipe.W.ld))
                 if getattr(pipe, "_compact", None) is not None else (
-                    "link-compact: %d of %d links have columns (%.1f GB resident)" % (
-                        int((pipe._link_pos >= 0).sum()), len(pipe._link_pos), 8e-9 * pipe.W.rows * pipe.W.ld)
-                    if getattr(pipe, "_link_pos", None) is not None else "dense"),
+                    ("force-compact: force rows %d columns (one line per four links) in front of the torque rows' %d%s; %.1f GB resident"
+                     % (pipe._force_ld, pipe.W.ld, (", link-compact: %d of %d links have columns" % (
+                         int((pipe._link_pos >= 0).sum()), len(pipe._link_pos))) if getattr(pipe, "_link_pos", None) is not None else "",
+                        8e-9 * pipe.W.buf.size))
+                    if getattr(pipe, "_force_ld", 0) else (
+                        "link-compact: %d of %d links have columns (%.1f GB resident)" % (
+                            int((pipe._link_pos >= 0).sum()), len(pipe._link_pos), 8e-9 * pipe.W.rows * pipe.W.ld)
+                        if getattr(pipe, "_link_pos", None) is not None else "dense")),
                 "active_row_blocks": row_blocks,
                 "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
                 "null_pivots": ("on: columns null to tol_qr / 64 skip their column steps (figh_tsqr_null_pivot_tol)"
