@@ -336,11 +336,12 @@ class IdentificationPipeline:
                 if wls:
                     raise NotImplementedError("wls=True needs the regressor resident in HBM (no chunk_samples)")
                 return self._run_chunked(strings)
-            if wls and getattr(self, "_force_ld", 0):
+            if wls and not getattr(self, "_no_force_compact", False):
                 # the weighted solve's second pass reads W as ONE matrix: from now on without the force-compact region
                 self._no_force_compact = True
-                self.W.buf.free()
-                self.W = None
+                if getattr(self, "_force_ld", 0) and self.W is not None:
+                    self.W.buf.free()
+                    self.W = None
             # (with the WLS the expression strings of the base parameters -- host work, 0.2 - 0.4 ms for TIAGo -- are built while
             # the weighted factorisation runs on the device)
             out = self._run_resident(strings and not wls, wls)
@@ -642,6 +643,24 @@ class IdentificationPipeline:
             buf = self._d_block_tri = _lib.DeviceArray((need,), np.float64)
         return buf
 
+    def _sb(self, name, count, dtype=np.float64):
+        """A device scratch buffer of this pipeline, kept from pass to pass (figh_malloc / figh_free synchronise the stream:
+        six of them per weighted solve were 0.3 ms of a 14 ms TIAGo step)."""
+        pool = self.__dict__.setdefault("_scratch", {})
+        buf = pool.get(name)
+        if buf is None or buf.size != int(count) or buf.dtype != np.dtype(dtype):
+            if buf is not None:
+                buf.free()
+            buf = pool[name] = _lib.DeviceArray((int(count),), dtype)
+        return buf
+
+    def _up(self, name, host):
+        """``host`` (1-D array) in the scratch buffer ``name``."""
+        host = np.ascontiguousarray(host)
+        buf = self._sb(name, host.size, host.dtype)
+        _lib.check(_lib.load().figh_memcpy_h2d(buf.ptr, host.ctypes.data, host.nbytes))
+        return buf
+
     def _wls(self, out, strings=False):
         """Weighted least squares of examples/staubli_TX40/identification.py:305-346 (what
         identification_tools.weighted_least_squares_blocks does on a host W_b), device-resident:
@@ -667,10 +686,10 @@ class IdentificationPipeline:
         # [residual norms of the nblocks row blocks | this rank's rows per block]: one sum over the ranks gives both -- the
         # shards of a run need not be equally long (dist.shard_range), so the divisor is the summed row count, not
         # rows_blk * world_size
-        d_r2 = _lib.DeviceArray((nblocks + 1,), np.float64)
+        d_r2 = self._sb("wls_r2", nblocks + 1)
         _rows = np.array([float(rows_blk)])
         _lib.check(_lib.load().figh_memcpy_h2d(d_r2.ptr + 8 * nblocks, _rows.ctypes.data, 8))
-        d_Rw = _lib.DeviceArray(((nb_par + 1) * (nb_par + 1),), np.float64)
+        d_Rw = self._sb("wls_Rw", (nb_par + 1) * (nb_par + 1))
         kept = np.flatnonzero(self._kept_cache[0])
         if getattr(self, "_have_block_tri", False):
             # the compact stack of the pass: block j holds its n_j + 1 triangle rows over the kept columns + tau
@@ -680,13 +699,13 @@ class IdentificationPipeline:
             v = np.zeros(nc)
             v[base] = phi_b
             v[n] = -1.0
-            _lib.block_rows_residuals(tri, row_off, nc, _lib.DeviceArray.from_host(v), d_r2)
+            _lib.block_rows_residuals(tri, row_off, nc, self._up("wls_v", v), d_r2)
             r2 = np.asarray(ex.sum_columns(d_r2, nblocks + 1))
             sig2 = r2[:nblocks] / r2[nblocks]
             if self.row_blocks is not None:  # (blocks without measurements: no rows in the stack, no variance)
                 inactive = counts == 0
                 sig2 = np.where(inactive, 1.0, sig2)
-            d_cols = _lib.DeviceArray.from_host(np.r_[base, n].astype(np.int32))
+            d_cols = self._up("wls_cols", np.r_[base, n].astype(np.int32))
             _lib.tsqr(tri, int(row_off[-1]), nc, d_cols, nb_par + 1, None, np.repeat(1.0 / np.sqrt(sig2), counts), d_Rw)
             if self.row_blocks is not None:
                 sig2 = sig2[self.row_blocks]
@@ -694,18 +713,17 @@ class IdentificationPipeline:
         else:
             if self._compact is not None or self.row_blocks is not None:
                 raise RuntimeError("block-compact W / row_blocks without per-row-block triangles")
-            d_cols = _lib.DeviceArray.from_host(np.asarray(self.device_columns(kept[base]), dtype=np.int32))
-            d_est = _lib.DeviceArray((W.rows,), np.float64)
-            _lib.matvec(W.buf, W.rows, W.ld, d_cols, nb_par, _lib.DeviceArray.from_host(phi_b), d_est)
+            d_cols = self._up("wls_cols", np.asarray(self.device_columns(kept[base]), dtype=np.int32))
+            d_est = self._sb("wls_est", W.rows)
+            _lib.matvec(W.buf, W.rows, W.ld, d_cols, nb_par, self._up("wls_phi", phi_b), d_est)
             _lib.block_sqnorm(self.d_tau, d_est, W.rows, nblocks, d_r2)
-            d_est.free()
             r2 = np.asarray(ex.sum_columns(d_r2, nblocks + 1))
             sig2 = r2[:nblocks] / r2[nblocks]
             _lib.tsqr(W.buf, W.rows, W.ld, d_cols, nb_par, self.d_tau, 1.0 / np.sqrt(sig2), d_Rw)
             source = "second pass over W"
         if getattr(ex, "collective", True) and ex.world_size > 1:
             d_stack, count = ex.stack_triangles(d_Rw, nb_par + 1)
-            d_one = _lib.DeviceArray(((nb_par + 1) * (nb_par + 1),), np.float64)
+            d_one = self._sb("wls_one", (nb_par + 1) * (nb_par + 1))
             _lib.tsqr_merge(d_stack, count, nb_par + 1, d_one)
             d_Rw = d_one
         if strings and "params_base" not in out:  # (the device is busy with the weighted factorisation meanwhile)
