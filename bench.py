@@ -356,9 +356,9 @@ def main():
                  # tree models: q, v, a re-laid per 64-sample tile once after the upload (figh_repack_samples), part of
                  # "device-resident q, v, a -> result" but not of the repeated pass (the copies stay resident)
                  "repack_inputs_ms": getattr(pipe, "repack_ms", 0.0)}
-    if rank == 0 and pipe.W is not None and getattr(pipe, "_compact", None) is None and pipe.W.rows * pipe.W.ld * 8 <= 8e9:
+    if rank == 0 and pipe.W is not None and getattr(pipe, "_compact", None) is None and pipe.W.buf.size * 8 <= 8e9:
         # what the drop-in boundary pays when W itself is handed back to a NumPy caller (never part of `value`)
-        host_W = np.empty(pipe.W.rows * pipe.W.ld)
+        host_W = np.empty(pipe.W.buf.size)  # (the resident buffer: force-compact W is smaller than rows x ld)
         _lib.synchronize()
         td = time.perf_counter()
         _lib.check(lib.figh_memcpy_d2h(host_W.ctypes.data, pipe.W.buf.ptr, host_W.nbytes))
