@@ -458,7 +458,7 @@ def main():
     # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
     # tools/pmc_summary.py), i.e. from the builder's run, not from this one
     try:
-        pmc_file = next(n for n in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
+        pmc_file = next(n for n in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
                         if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
@@ -470,7 +470,7 @@ def main():
                     roof[key]["traffic_source"] = ("profiles/%s: a committed rocprofv3 --pmc run of this command, NOT "
                                                    "measured in this run" % pmc_file)
         if args.config == "cfg4" and N == 4_000_000:
-            pmc4 = next(n for n in ("r04_pmc_summary_cfg4.json", "r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
+            pmc4 = next(n for n in ("r05_pmc_summary_cfg4.json", "r04_pmc_summary_cfg4.json", "r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
                         if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", pmc4)) as f:
                 pmc = json.load(f)
