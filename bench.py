@@ -476,7 +476,9 @@ def main():
                 pmc = json.load(f)
             src = "profiles/%s: a committed rocprofv3 --pmc run of this command, NOT measured in this run" % pmc4
             wy = next((n for n in ("tsqr_wy_kernel<4, 5, 4, 2, true, 0>", "tsqr_wy_kernel<4, 5, 4, 2, true>") if n in pmc), "")
-            for key, kname in (("regressor_tree", "regressor_tape_kernel<16, true, true, true, true>"), ("tsqr", wy)):
+            k1p = next((n for n in ("regressor_tape_kernel<16, true, true, true, true, true>",
+                                    "regressor_tape_kernel<16, true, true, true, true>") if n in pmc), "")
+            for key, kname in (("regressor_tree", k1p), ("tsqr", wy)):
                 if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
                     roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
                     roof[key]["traffic_source"] = src + (" (the torque-row launch of the two level-0 launches)" if key == "tsqr" else "")
