@@ -173,8 +173,14 @@ __device__ __forceinline__ void wy_factor_panel(double (&X)[RPL], double *__rest
                                                 double *__restrict__ Vl, double *__restrict__ Tl, const int lane,
                                                 const int c, const int g, const double null2) {
     double myinv = 0.0;
+    {
+        // (a zero made HERE: hoisted out of the tile loop the constant lived in a register pair for the whole kernel, and the
+        // allocator spilled exactly that pair -- a scratch reload of 0.0 at the head of every panel chain)
+        double zero = 0.0;
+        asm volatile("" : "+v"(zero));
 #pragma unroll
-    for (int e = lane; e < 16 * kLdt; e += 64) Tl[e] = 0.0;
+        for (int e = lane; e < 16 * kLdt; e += 64) Tl[e] = zero;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
