@@ -374,18 +374,21 @@ __global__ __launch_bounds__(512) void fused_chain_tsqr_kernel(
 #endif
                 {
                     const int lo = 14 * j, width = NC - lo;
-                    // sixteen rows requested at a time (the LDS latency is paid four times per pass, not sixteen times)
+                    // RB rows requested at a time (the LDS latency is paid 64 / RB times per pass, not 64 times); sixteen where
+                    // the registers allow it -- with six links the producer is at the 256-register limit exactly here and
+                    // sixteen cost two spilled registers whose reloads wait behind the stores in flight: eight
+                    constexpr int RB = NJ >= 6 ? 8 : 16;
                     auto column_sum = [&](const double *col) {
                         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
-                        for (int r0 = 0; r0 < 64; r0 += 16) {
-                            double x[16];
+                        for (int r0 = 0; r0 < 64; r0 += RB) {
+                            double x[RB];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) x[r] = col[(r0 + r) * LDT];
+                            for (int r = 0; r < RB; ++r) x[r] = col[(r0 + r) * LDT];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(x[r]));
+                            for (int r = 0; r < RB; ++r) asm volatile("" : "+v"(x[r]));
 #pragma unroll
-                            for (int r = 0; r < 16; r += 4) {
+                            for (int r = 0; r < RB; r += 4) {
                                 t0 += x[r] * x[r];
                                 t1 += x[r + 1] * x[r + 1];
                                 t2 += x[r + 2] * x[r + 2];
