@@ -484,7 +484,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
     struct Slot {
         f64x4 t[NRC];
         unsigned boff;
-        int wcol;
         bool wlive, tlive;
     };
     Slot F, Q[NQ];
@@ -492,8 +491,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         const int col = 16 * (wave + NW * s) + c;
         S.wlive = col < n;
         S.tlive = col == n && tau != nullptr;
-        S.wcol = S.wlive ? (col_idx ? col_idx[col] : col) : 0;
-        S.boff = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)S.wcol);
+        const int wcol = S.wlive ? (col_idx ? col_idx[col] : col) : 0;  // (only boff travels with the slot)
+        S.boff = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)wcol);
 #pragma unroll
         for (int rc = 0; rc < NRC; ++rc) S.t[rc] = f64x4{0.0, 0.0, 0.0, 0.0};
     };
@@ -547,7 +546,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
         F = Q[0];                                                                      \
         _Pragma("unroll") for (int j = 0; j + 1 < NQ; ++j) Q[j] = Q[j + 1];            \
         Q[NQ - 1].boff = old_.boff;                                                    \
-        Q[NQ - 1].wcol = old_.wcol;                                                    \
         Q[NQ - 1].wlive = old_.wlive;                                                  \
         Q[NQ - 1].tlive = old_.tlive;                                                  \
         _Pragma("unroll") for (int rc = 0; rc < NRC; ++rc) Q[NQ - 1].t[rc] = old_.t[rc]; \
@@ -597,8 +595,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void tsqr_wy_kernel(const double *__r
             const int lcol = 16 * LC + lc_;
             L.wlive = lowner && lcol < n;
             L.tlive = lowner && lcol == n && tau != nullptr;
-            L.wcol = L.wlive ? (col_idx ? col_idx[lcol] : lcol) : 0;
-            L.boff = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)L.wcol);
+            const int lwcol = L.wlive ? (col_idx ? col_idx[lcol] : lcol) : 0;
+            L.boff = 8u * ((unsigned)g * (unsigned)ldw + (unsigned)lwcol);
         }
 #pragma unroll
         for (int rc = 0; rc < NRC; ++rc) L.t[rc] = f64x4{0.0, 0.0, 0.0, 0.0};
