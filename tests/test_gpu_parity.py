@@ -2455,3 +2455,35 @@ def test_pipeline_active_row_blocks(lib, oracle_lib, layout):
     phi_ref, res2 = np.linalg.lstsq(Wa[:, base], tau, rcond=None)[:2]
     assert abs(out["residual_norm"] - np.sqrt(res2[0])) <= 1e-9 * np.sqrt(res2[0])
     assert np.abs(out["phi_ls"] - phi_ref).max() <= 1e-6 * np.abs(phi_ref).max()
+
+
+def test_tiago_real_data_known_answers_hip(lib):
+    """The TIAGo known-answer replay (tests/test_oracle.py::test_tiago_real_data_known_answers) through the HIP path: the tree
+    kernel's regressor of the 5 870 real samples, the elimination, the active-joint decimation on the device and double_QR
+    reproduce the 44 expressions of the reference's committed, Pinocchio-produced tiago_bp_19_Oct_2024_2320.csv verbatim, its
+    values to the 6-decimal rounding and its standard deviations to their 2 decimals."""
+    from figaroh_plus_amd.identification.identification_tools import decimate_joint_blocks, relative_stdev
+    from figaroh_plus_amd.tools.qrdecomposition import double_QR
+    from figaroh_plus_amd.tools.regressor import build_regressor_basic, build_regressor_reduced, get_index_eliminate
+    from tiago_real_common import load_fixture, tiago, trajectories
+    z, meta = load_fixture()
+    g, robot, param, params_std = tiago()
+    p, v, a, tau = trajectories(z, meta, robot)
+    W = build_regressor_basic(robot, p, v, a, param)
+    chk = np.array([W.sum(), np.abs(W).sum(), (W * W).sum()])
+    assert np.abs(chk - z["W_checksum"]).max() <= 1e-11 * np.abs(z["W_checksum"]).max()
+    idx_e, params_r = get_index_eliminate(W, params_std, tol_e=meta["tol_e"])
+    assert list(idx_e) == z["idx_e"].tolist() and list(params_r) == meta["params_r"]
+    W_e = build_regressor_reduced(W, idx_e)
+    act = meta["act_idxv"]
+    W_list, tau_list = decimate_joint_blocks(W_e, tau.T.reshape(-1), len(act), q=10, stages=1, blocks=act)
+    W_rf, tau_rf = np.vstack(W_list), np.concatenate(tau_list)
+    assert np.abs(tau_rf - z["tau_rf"]).max() <= 1e-12 * np.abs(tau_rf).max()
+    assert np.abs(W_rf[::29] - z["W_rf_rows"]).max() <= 1e-10 * np.abs(W_rf).max()
+    W_b, bp, params_base, phi_b, phi_std = double_QR(tau_rf, W_rf, params_r, params_std)
+    assert list(params_base) == meta["csv_expressions"]
+    csvv = z["csv"]
+    assert np.abs(phi_b - csvv[:, 0]).max() <= 2e-6
+    assert np.abs(phi_std - z["phi_std"]).max() <= 2e-5
+    std = relative_stdev(W_b, phi_b, tau_rf)
+    assert np.abs(std - csvv[:, 1] / 100).max() <= 0.011

@@ -236,3 +236,41 @@ def test_tiago_active_joint_fixture_is_consistent_with_the_oracle():
     assert np.abs(colsq - z["raw_W_rf_colsq"]).max() <= 1e-10 * colsq.max()
     R = np.linalg.qr(Wa, mode="r")
     assert np.flatnonzero(np.abs(np.diag(R)) > 1e-8).tolist() == z["raw_idx_base"].tolist()
+
+
+def test_tiago_real_data_known_answers(oracle_lib):
+    """The reference's committed TIAGo measurements -> its committed, PINOCCHIO-PRODUCED result
+    (examples/tiago/data/identification/dynamic/tiago_bp_19_Oct_2024_2320.csv) through the oracle: the script's flow
+    (examples/tiago/identification.py: truncate, median + Butterworth filters, gradient accelerations, full configuration, motor
+    constants, regressor of all 24 dofs, elimination at 1e-3 on the full matrix, decimation of the eight ACTIVE row blocks,
+    double_QR) reproduces all 44 base-parameter expressions verbatim -- regrouping coefficients such as 0.113498, 0.15315,
+    0.076575 are functions of the tree's geometry as Pinocchio numbers and places it (prismatic torso 13, arm 14..20, the two
+    gripper fingers 21 / 22 mirrored on arm_7) -- and the identified values and standard deviations to the file's digits.  This
+    pins the restated regressor of a TREE on a Pinocchio output, as TX40_bp_5.csv does for chains."""
+    from tiago_real_common import load_fixture, tiago, trajectories
+    z, meta = load_fixture()
+    g, robot, param, params_std = tiago()
+    assert abs(meta["torso_subtree_mass"] - sum(robot.model.inertias[j].mass for j in range(13, 25))) <= 1e-12
+    p, v, a, tau = trajectories(z, meta, robot)
+    N = len(p)
+    assert np.array_equal(p[::499], z["p_rows"]) and np.array_equal(v[::499], z["v_rows"])
+    assert np.array_equal(a[::499], z["a_rows"])
+    mode, flags, ft = oracle_lib.param_flags(param, False)
+    W = oracle_lib.OracleModel(g.flat()).build_regressor_basic(p, v, a, mode, flags, ft)  # (the C oracle: 5 870 x 24 dofs)
+    chk = np.array([W.sum(), np.abs(W).sum(), (W * W).sum()])
+    assert np.abs(chk - z["W_checksum"]).max() <= 1e-11 * np.abs(z["W_checksum"]).max()
+    idx_e, params_r = oracle_np.get_index_eliminate(W, list(params_std.keys()), meta["tol_e"])
+    assert list(idx_e) == z["idx_e"].tolist() and params_r == meta["params_r"]
+    W_e = np.delete(W, idx_e, 1)
+    act = meta["act_idxv"]
+    W_act = np.vstack([W_e[b * N:(b + 1) * N] for b in act])
+    W_list, tau_list = oracle_np.decimate_joint_blocks(W_act, tau.T.reshape(-1), len(act), q=10, stages=1)
+    W_rf, tau_rf = np.vstack(W_list), np.concatenate(tau_list)
+    assert np.abs(tau_rf - z["tau_rf"]).max() <= 1e-12 * np.abs(tau_rf).max()
+    assert np.abs(W_rf[::29] - z["W_rf_rows"]).max() <= 1e-10 * np.abs(W_rf).max()
+    res = oracle_np.base_parameters(W_rf, params_r, tau=tau_rf)
+    assert res["params_base"] == meta["csv_expressions"]          # the 44 committed expressions, in order
+    csvv = z["csv"]
+    assert np.abs(res["phi_b"] - csvv[:, 0]).max() <= 2e-6         # committed values (6 decimals)
+    std = oracle_np.relative_stdev(res["W_b"], res["phi_b"], tau_rf)
+    assert np.abs(std - csvv[:, 1] / 100).max() <= 0.011           # committed 100 x std% (2 decimals)
