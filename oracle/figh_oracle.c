@@ -8,8 +8,9 @@
  *                                  un-vendored, version un-pinned: environment.yml:7), as called at
  *                                  src/figaroh/tools/regressor.py:49-51 and :93-95.  Floating-point
  *                                  parity with Pinocchio itself is UNPINNED (not installable here);
- *                                  pinned through RNEA identity + the reference's committed base-
- *                                  parameter expressions, see oracle_np.py.
+ *                                  pinned through RNEA identity + the reference's committed, Pinocchio-
+ *                                  produced base-parameter files (TX40 chain, TIAGo tree: expressions
+ *                                  verbatim, values exact), see oracle_np.py.
  *  oracle_build_regressor_basic    src/figaroh/tools/regressor.py:20-194 (+ :198-227 coupling)
  *  oracle_colsq                    diag(W^T W) of regressor.py:243,271
  *  oracle_householder_r            unblocked Householder QR (what LAPACK dgeqr2 does inside

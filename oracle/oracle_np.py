@@ -21,7 +21,12 @@ What is restated, and what pins it
   ``examples/staubli_TX40/results/TX40_bp_5.csv``, the TIAGo joint numbering and
   the human body list, and (iii) the NUMBERS of that CSV (phi_OLS, sigma%, phi_WLS),
   reproduced from the reference's committed TX40 measurements to <= 3.8e-4
-  (``oracle/gen_golden_tx40_real.py``, ``tests/test_oracle.py::test_tx40_real_data_known_answers``).
+  (``oracle/gen_golden_tx40_real.py``, ``tests/test_oracle.py::test_tx40_real_data_known_answers``), and (iv) for
+  fixed-base TREES the reference's committed, Pinocchio-produced TIAGo result
+  ``examples/tiago/data/identification/dynamic/tiago_bp_19_Oct_2024_2320.csv``: the TIAGo script replayed on the
+  committed TIAGo measurements reproduces its 44 expressions verbatim and its values / sigma% exactly at the
+  file's precision (``oracle/gen_golden_tiago_real.py``, ``test_tiago_real_data_known_answers``).  What no Pinocchio
+  output pins is the free-flyer frame convention (the reference commits no floating-base result).
 * everything else (row/column layout, elimination, QR bookkeeping, strings,
   LS/WLS/sigma) restates plain NumPy code of the reference and is pinned against
   outputs of the reference itself (``tests/golden/*.npz``).
