@@ -60,7 +60,15 @@ enum : int32_t { OP_RESET = 0, OP_STEP = 1, OP_EMIT = 2, OP_ZERO = 3, OP_TX40 = 
 enum : int32_t { STEP_JSTART = 1 };
 // EMIT flags (field c)
 enum : int32_t { EMIT_INERT = 1, EMIT_EXTRA = 2, EMIT_OWN = 4, EMIT_FLUSH = 8, EMIT_NOSTORE = 16 };
-constexpr int kFetch = 5;  // joints per FETCH group (the five payload fields of an op)
+// joints per FETCH group (at most five: the payload fields of an op).  The free-flyer walk (one EMIT per STEP, state in ~250 registers
+// at one wave per SIMD) is fastest with five; the joint-torque walks carry kRowSlots axes and gain more from the registers
+// (same-box A/B, tools/var_run.sh: TIAGo K1' 2.71 / 2.43 / 2.51 ms with 4 / 3 / 2; human K1' 26.7 -> 30.8 ms with three)
+__host__ __device__ constexpr int fetch_group(bool extff) { return extff ? 5 : 3; }
+// Row slots of a walk (joint-torque mode): one walk over the subtree of a joint serves the row blocks of that joint AND of the
+// joints up to kRowSlots - 1 levels below it -- the axis of every such row joint is carried down the tree in its slot (= its depth
+// below the top of the walk), and a link is emitted once per slot it lies under.  With one slot a tree of depth d steps onto
+// O(d) joints per row block and link (TIAGo: 195 forward steps per sample for 24 joints; three slots: 69, five: 51).
+constexpr int kRowSlots = 5;
 
 struct TapeOp {
     int32_t op, a, b, c, d, e;
@@ -193,7 +201,7 @@ __device__ __forceinline__ void stream_zeros(const int lane, const int nvalid, d
 // of the force-row lines, 5/8 of W (TALOS 101 -> 64 GB, human 146 -> 92 GB), and the force rows' TSQR reads 16-column groups
 // that are all payload.  W = force region, torque region at W + 3 N ldf with leading dimension ldw.
 template <int LS, bool EXTFF, bool VEC2, bool STORE, bool COLSQ, bool FC = false>
-__global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__restrict__ M,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FC ? 1 : 2))) void regressor_tape_kernel(const DevModel *__restrict__ M,
                                                             const TapeOp *__restrict__ tape, const int ntape,
                                                             const int flags, const long N,
                                                             const double *__restrict__ q, const double *__restrict__ v,
@@ -246,9 +254,16 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
         // state of the current link
         double V[6] = {0, 0, 0, 0, 0, 0}, A[6] = {-g0, -g1, -g2, 0, 0, 0};
         double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};  // EXTFF: link -> root-joint frame
-        double Jl[3] = {0, 0, 0}, Ja[3] = {0, 0, 0};                    // otherwise: the row's joint axis, link frame
-        bool jactive = false;
+        // otherwise: the axes of the walk's row joints (slot = depth below the top of the walk), link frame; jmask = slots in use
+        constexpr int NS = EXTFF ? 1 : kRowSlots;
+        double Jl[NS][3], Ja[NS][3];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) Jl[s][d] = Ja[s][d] = 0.0;
+        int jmask = 0;
         // inputs of the coming single-dof joints (FETCH): q (cos q for a continuous joint), sin q, qd, qdd
+        constexpr int kFetch = fetch_group(EXTFF);
         double sq0[kFetch], sq1[kFetch], sqd[kFetch], sqdd[kFetch];
 #pragma unroll
         for (int s = 0; s < kFetch; ++s) sq0[s] = sq1[s] = sqd[s] = sqdd[s] = 0.0;
@@ -360,26 +375,34 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                         for (int d = 0; d < 3; ++d) pc[d] += pn[d];
                     }
                 } else {
-                    if (ob & STEP_JSTART) {  // the row's own joint: the axis of its dof, in its own frame
+                    // push the axes of the row joints above one link down: J <- liMi^-1 J
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        if ((jmask >> s) & 1) {
+                            double nJl[3], nJa[3];
+                            cross3(pk, Ja[s], t1);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) t2[d] = Jl[s][d] - t1[d];
+                            rotT(Rk, t2, nJl);
+                            rotT(Rk, Ja[s], nJa);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                Jl[s][d] = nJl[d];
+                                Ja[s][d] = nJa[d];
+                            }
+                        }
+                    if (ob & STEP_JSTART) {  // a row's own joint (slot oc): the axis of its dof, in its own frame
                         const bool pris = jt == FIGH_JT_PRISMATIC;
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            Jl[d] = pris ? ax[d] : 0.0;
-                            Ja[d] = pris ? 0.0 : ax[d];
-                        }
-                        jactive = true;
-                    } else if (jactive) {  // push the axis one link down: J <- liMi^-1 J
-                        double nJl[3], nJa[3];
-                        cross3(pk, Ja, t1);
+                        for (int s = 0; s < NS; ++s)
+                            if (s == oc) {
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) t2[d] = Jl[d] - t1[d];
-                        rotT(Rk, t2, nJl);
-                        rotT(Rk, Ja, nJa);
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            Jl[d] = nJl[d];
-                            Ja[d] = nJa[d];
-                        }
+                                for (int d = 0; d < 3; ++d) {
+                                    Jl[s][d] = pris ? ax[d] : 0.0;
+                                    Ja[s][d] = pris ? 0.0 : ax[d];
+                                }
+                            }
+                        jmask = (jmask & ((1 << oc) - 1)) | (1 << oc);  // (deeper slots belong to a branch that was left)
                     }
                 }
                 // A STEP that is followed by the EMIT of its link runs it in the SAME iteration: every trip through the loop
@@ -396,6 +419,9 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                 }
             }
             if (op == OP_EMIT) {
+              // (the EMITs of one link -- one per row slot it lies under -- run back to back inside this iteration, for the same reason)
+              bool more = false;
+              do {
                 // ---- the segment of link oa: EXTFF in all six row blocks (od = components with inertial entries),
                 // otherwise in row block ob
                 // (external wrench with FIGH_FLAG_LINK_COMPACT: the link's segment sits at its position among the links that
@@ -488,7 +514,19 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                             }
                         }
                     } else {
-                        if (oc & EMIT_INERT) axis_times_body_regressor(Jl, Ja, accv, A + 3, V + 3, o);
+                        if (oc & EMIT_INERT) {
+                            double jl[3] = {0, 0, 0}, ja[3] = {0, 0, 0};
+#pragma unroll
+                            for (int s = 0; s < NS; ++s)
+                                if (s == (oc >> 8)) {
+#pragma unroll
+                                    for (int d = 0; d < 3; ++d) {
+                                        jl[d] = Jl[s][d];
+                                        ja[d] = Ja[s][d];
+                                    }
+                                }
+                            axis_times_body_regressor(jl, ja, accv, A + 3, V + 3, o);
+                        }
                     }
 #pragma unroll
                     for (int d = 0; d < 10; ++d) my[d] = o[d];
@@ -527,11 +565,21 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
+                more = !EXTFF && pcnt + 1 < ntape && tape[pcnt + 1].op == OP_EMIT;  // (the free-flyer walk emits a link once)
+                if (more) {
+                    ++pcnt;
+                    oa = tape[pcnt].a;
+                    ob = tape[pcnt].b;
+                    oc = tape[pcnt].c;
+                    od = tape[pcnt].d;
+                    oe = tape[pcnt].e;
+                }
+              } while (more);
             } else if (op == OP_ZERO) {
                 if constexpr (STORE)
                     stream_zeros<VEC2>(lane, nvalid, W, ldw, ldw8, (long)oa * N + i0, ob, oc, (unsigned)od, (unsigned)oe);
             } else if (op == OP_FETCH) {
-                const int js[kFetch] = {oa, ob, oc, od, oe};
+                const int js[5] = {oa, ob, oc, od, oe};
 #pragma unroll
                 for (int s = 0; s < kFetch; ++s)
                     if (js[s] > 0) {
@@ -548,7 +596,7 @@ __global__ __launch_bounds__(64) void regressor_tape_kernel(const DevModel *__re
 #pragma unroll
                 for (int d = 0; d < 9; ++d) Rc[d] = (d % 4 == 0) ? 1.0 : 0.0;
                 pc[0] = pc[1] = pc[2] = 0.0;
-                jactive = false;
+                jmask = 0;
             } else if (op == OP_TX40) {  // (regressor.py:198-227, fused): columns 14 nl .. + 2 on the six joint rows
                 if constexpr (STORE) {
                     if (lane < nvalid) {
@@ -626,13 +674,13 @@ struct TapeBuilder {
 
 // Insert the FETCH ops: the single-dof STEPs are grouped by kFetch in tape order, each group's joint inputs are loaded
 // by one FETCH in front of its first STEP, and every STEP learns its slot (bits 8.. of its flags field).
-std::vector<TapeOp> with_fetches(const DevModel &h, const std::vector<TapeOp> &in) {
+std::vector<TapeOp> with_fetches(const DevModel &h, const std::vector<TapeOp> &in, const int kFetch) {
     std::vector<TapeOp> out;
     out.reserve(in.size() + in.size() / kFetch + 1);
     auto fetched = [&](const TapeOp &op) { return op.op == OP_STEP && h.jtype[op.a] != FIGH_JT_FREEFLYER; };
     size_t i = 0;
     while (i < in.size()) {
-        int js[kFetch] = {0, 0, 0, 0, 0};
+        int js[5] = {0, 0, 0, 0, 0};
         int cnt = 0;
         size_t j = i;
         for (; j < in.size() && cnt < kFetch; ++j)
@@ -696,7 +744,7 @@ std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, 
     }
     flush_zero(h.njoints);
     if (force_compact && last_emit >= 0) T.ops[last_emit].c |= EMIT_FLUSH;  // (a last group of fewer than four links)
-    return with_fetches(h, T.ops);
+    return with_fetches(h, T.ops, fetch_group(true));
 }
 
 // One row block per dof.  Joint-torque mode: every joint is single-dof and has its row.  External wrench on a fixed
@@ -754,7 +802,71 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
         compact_prefix += ld_row;
     }
     if (flags & FIGH_FLAG_TX40) T.push(OP_TX40, ls * nl);
-    return with_fetches(h, T.ops);
+    return with_fetches(h, T.ops, fetch_group(false));
+}
+
+// Joint-torque mode (every joint single-dof, one row block per joint): walks with kRowSlots row slots.  A walk has a top
+// joint t; it steps down from the root to t and then over the subtree of t, and serves the row blocks of the joints of that
+// subtree that lie fewer than kRowSlots levels below t (slot = levels below t).  A link is emitted once per served row joint
+// above it (its own row first: Ia / fv / fs / off read the inputs of the joint stepped last).  Joints that are deeper become
+// the tops of their own walks.  The zero runs of a row block (links outside its joint's subtree) do not depend on the walks.
+std::vector<TapeOp> build_tape_torque_rows(const DevModel &h, int flags, int ls, unsigned long long active_rows) {
+    TapeBuilder T(h);
+    const bool extras = flags & (FIGH_FLAG_FRICTION | FIGH_FLAG_ACT_INERTIA | FIGH_FLAG_OFFSET);
+    const bool compact = (flags & FIGH_FLAG_COMPACT_BLOCKS) != 0;
+    const int nl = h.nlinks, nj = h.njoints;
+    std::vector<int> depth(nj, 0), s1(nj, 0), ld_row(h.nv, 0), prefix(h.nv, 0), joint_of_row(h.nv, 0);
+    for (int j = 1; j < nj; ++j) {
+        depth[j] = h.parents[j] > 0 ? depth[h.parents[j]] + 1 : 0;
+        s1[j] = T.subtree_end(j);
+        joint_of_row[h.idx_v[j]] = j;
+    }
+    auto stored = [&](int row) { return ((active_rows >> row) & 1ull) != 0; };
+    int compact_prefix = 0;
+    for (int row = 0; row < h.nv; ++row) {  // block-compact: a row block's own leading dimension, 0 when it is not stored
+        const int j = joint_of_row[row];
+        ld_row[row] = stored(row) ? ls * (s1[j] - j) : 0;
+        prefix[row] = compact_prefix;
+        compact_prefix += ld_row[row];
+    }
+    if (!(flags & (FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS)))
+        for (int row = 0; row < h.nv; ++row) {
+            if (!stored(row)) continue;
+            const int j = joint_of_row[row];
+            T.zero(row, 0, ls * (j - 1));
+            T.zero(row, ls * (s1[j] - 1), ls * (nl + 1 - s1[j]));
+        }
+    std::vector<char> served(nj, 0);
+    for (int t = 1; t < nj; ++t) {
+        if (served[t]) continue;
+        auto in_walk = [&](int k) { return k >= t && k < s1[t] && depth[k] - depth[t] < kRowSlots; };
+        for (int k = t; k < s1[t]; ++k)
+            if (in_walk(k)) served[k] = 1;
+        auto step = [&](int k) { T.push(OP_STEP, k, in_walk(k) ? STEP_JSTART : 0, in_walk(k) ? depth[k] - depth[t] : 0); };
+        int prev = -1;
+        for (int b = t; b < s1[t]; ++b) {
+            if (b == t || h.parents[b] != prev) {  // a new branch: down from the root again
+                T.push(OP_RESET);
+                for (int k : T.path_to(h.parents[b])) step(k);
+            }
+            step(b);
+            prev = b;
+            std::vector<int> rows;  // the served row joints above the link, its own one first
+            if (in_walk(b)) rows.push_back(b);
+            for (int k = h.parents[b]; k >= t && k > 0; k = h.parents[k])
+                if (in_walk(k)) rows.push_back(k);
+            for (int j : rows) {
+                const int row = h.idx_v[j];
+                const bool extra = extras && b == j;
+                T.push(OP_EMIT, b, row,
+                       EMIT_INERT | (extra ? EMIT_EXTRA : 0) | (b == j ? EMIT_OWN : 0) | (stored(row) ? 0 : EMIT_NOSTORE) |
+                           ((depth[j] - depth[t]) << 8),
+                       (compact && stored(row)) ? ((ls * (b - j) + 1) | (ld_row[row] << 16)) : 0, compact ? prefix[row] : 0);
+            }
+        }
+    }
+    if (flags & FIGH_FLAG_TX40) T.push(OP_TX40, ls * nl);
+    return with_fetches(h, T.ops, fetch_group(false));
 }
 
 struct DeviceTape {
@@ -850,7 +962,9 @@ int launch_regressor_tree(const figh_model_s *m, int mode, int flags, int ft_mas
     auto it = g_tapes.find(key);
     if (it == g_tapes.end()) {
         std::vector<TapeOp> ops = extff ? build_tape_extff(h, flags, ft_mask, ls, nlive >= 0 ? link_pos : nullptr, fc)
-                                        : build_tape_rows(h, mode, flags, ft_mask, ls, m->active_rows);
+                                        : (mode == FIGH_MODE_JOINT_TORQUE && h.nv == h.njoints - 1
+                                               ? build_tape_torque_rows(h, flags, ls, m->active_rows)
+                                               : build_tape_rows(h, mode, flags, ft_mask, ls, m->active_rows));
 #ifdef FIGH_ABLATION
         {
             const int hot = getenv("FIGH_TREE_HOTIN") != nullptr;
