@@ -89,6 +89,54 @@ void *workspace(size_t bytes, int slot) {
     return g_ws[slot];
 }
 
+static hipStream_t g_side_stream = nullptr;
+static hipEvent_t g_fork_event = nullptr, g_join_event = nullptr;
+
+SideStream::SideStream() {
+    if (!g_side_stream) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
+        if (hipStreamCreateWithPriority(&g_side_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
+            hipEventCreateWithFlags(&g_fork_event, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) != hipSuccess) {
+            g_side_stream = nullptr;
+            (void)hipGetLastError();
+            return;
+        }
+    }
+    main_ = g_stream;
+    if (hipEventRecord(g_fork_event, main_) != hipSuccess || hipStreamWaitEvent(g_side_stream, g_fork_event, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    g_stream = g_side_stream;
+    ok_ = open_ = true;
+}
+
+hipEvent_t SideStream::finish() {
+    if (!open_) return nullptr;
+    open_ = false;
+    const hipError_t e = hipEventRecord(g_join_event, g_side_stream);
+    g_stream = main_;
+    if (e != hipSuccess) {  // (cannot order the streams by an event: wait for the side work here)
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(g_side_stream);
+        return nullptr;
+    }
+    return g_join_event;
+}
+
+SideStream::~SideStream() {
+    if (open_) stream_wait(finish());
+}
+
+void stream_wait(hipEvent_t ev) {
+    if (ev && hipStreamWaitEvent(g_stream, ev, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(g_side_stream);
+    }
+}
+
 static LaunchEvents g_launch_events;
 static bool g_launch_events_taken = false;
 

@@ -76,6 +76,21 @@ LaunchEvents take_launch_events();  // the pair of the innermost at_launch scope
 // scratch buffer owned by the library, grown on demand (device)
 void *workspace(size_t bytes, int slot);
 
+// A second, high-priority stream for LATENCY-BOUND chains of small launches (the merge levels of a TSQR: a handful of
+// workgroups per launch, 45 .. 500 us per level whatever the number of pairs) that do not depend on the throughput-bound
+// launch the library stream runs meanwhile.  Inside the scope stream() is the side stream, which starts behind everything
+// queued on the library stream so far; finish() switches back and returns the event that marks the end of the side work --
+// the library stream waits for it (stream_wait) where it first needs the results.  Not nested.
+struct SideStream {
+    SideStream();
+    ~SideStream();  // finish() + stream_wait() when finish() was not called
+    hipEvent_t finish();
+    bool ok() const { return ok_; }
+    bool ok_ = false, open_ = false;
+    hipStream_t main_ = nullptr;
+};
+void stream_wait(hipEvent_t ev);
+
 }  // namespace figh
 
 // internal (not part of include/figh.h, not exported by libfigh.so: hidden visibility): level 0 of the TSQR only, see
@@ -147,7 +162,9 @@ struct WyPairStack {  // one stack to reduce to one triangle
     double *out;
 };
 int reduce_wide_stacks(std::vector<WyPairStack> &stacks);
-int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus);
+// (before_embed: an event the stream waits for in front of the embedding launch -- the only launch that writes outside the
+// group's own workspaces)
+int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus, hipEvent_t before_embed = nullptr);
 // figh_linalg.hip: stack of `count` compact nc x nc triangles -> one; tol_qr >= 0: + rank decision and regrouped rows
 // ((nc + 1) x nc doubles, layout in figh.h, figh_tsqr_selected), else the plain triangle
 int tsqr_reduce_stack(const double *d_Rs, long count, int nc, int n_free, double tol_qr, double *d_out);

@@ -1082,6 +1082,27 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     int narrow = 0;
     for (int j = 0; j < nblocks; ++j) narrow += (h_counts[j] >= 1 && h_counts[j] + (d_tau ? 1 : 0) <= 64) ? 1 : 0;
     const bool grouped = narrow >= 4 && rows_b >= 64 * 64;
+    // With a grouped launch behind them, the merge levels of the other blocks -- latency-bound chains of small launches, 2.4 ms
+    // of TIAGo's 12.3 ms step -- run on the side stream WHILE the library stream runs the grouped level 0 (throughput-bound,
+    // 1.6 ms): every such block keeps its level-0 triangles (its own region instead of the shared tri_b) until all level-0
+    // launches are queued, then the side stream reduces and embeds them; the grouped embedding -- the only launch of the group
+    // that writes into the stack -- waits for the side work (a per-block embedding zero-fills nc rows from its offset).
+    const bool overlap = grouped;
+    struct MidStack {
+        double *tri;
+        long cnt;
+        int ncj;
+        double *R;
+    };
+    std::vector<MidStack> mids;
+    size_t mid_doubles = 0, mid_at = 0;
+    if (overlap)
+        for (int j = 0; j < nblocks; ++j) {
+            const int ncj = h_counts[j] + (d_tau ? 1 : 0);
+            if (h_counts[j] > 0 && ncj > 64 && ncj <= 80) mid_doubles += (size_t)ncj * ncj * (size_t)figh_tsqr_level0_capacity(ncj);
+        }
+    double *mid_tri = mid_doubles ? static_cast<double *>(workspace(sizeof(double) * mid_doubles, 38)) : nullptr;
+    if (mid_doubles && !mid_tri) return FIGH_ERR_ALLOC;
     long row_off = 0, off = 0;
     for (int j = 0; j < nblocks; ++j) {
         const int nj = h_counts[j], ncj = nj + (d_tau ? 1 : 0);
@@ -1120,6 +1141,18 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
             off += nj;
             continue;
         }
+        if (overlap && nj > 0 && ncj > 64) {  // (65 .. 80 columns: the register-tile kernel; reduced on the side stream)
+            const int64_t cap_j = figh_tsqr_level0_capacity(ncj);
+            double *tri_j = mid_tri + mid_at;
+            mid_at += (size_t)ncj * ncj * (size_t)cap_j;
+            if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_j, cap_j, &cnt, nullptr))
+                return rc;
+            mids.push_back({tri_j, (long)cnt, ncj, Rb});
+            embeds.push_back({Rb, ncj, nj, d_pos + off, stack + (size_t)row_off * nc});
+            row_off += ncj;
+            off += nj;
+            continue;
+        }
         if (nj > 0) {
             if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr))
                 return rc;
@@ -1136,11 +1169,31 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         row_off += ncj;
         off += nj;
     }
-    if (int rc = reduce_wide_stacks(wide)) return rc;
-    for (const Embed &e : embeds)
-        if (int rc = embed_force_triangle(e.R, e.ncj, e.nj, e.pos, nc, n, e.out)) return rc;
-    if (!jobs.empty())
-        if (int rc = launch_tsqr_group(jobs, nc, n, cu_count())) return rc;
+    auto reduce_and_embed = [&]() -> int {
+        for (const MidStack &ms : mids) {
+            if (ms.cnt == 1)
+                FIGH_HIP(hipMemcpyAsync(ms.R, ms.tri, sizeof(double) * (size_t)ms.ncj * ms.ncj, hipMemcpyDeviceToDevice, stream()));
+            else if (int rc = tsqr_reduce(ms.tri, ms.cnt, ms.ncj, ms.R))
+                return rc;
+        }
+        if (int rc = reduce_wide_stacks(wide)) return rc;
+        for (const Embed &e : embeds)
+            if (int rc = embed_force_triangle(e.R, e.ncj, e.nj, e.pos, nc, n, e.out)) return rc;
+        return FIGH_OK;
+    };
+    if (overlap && !jobs.empty() && !embeds.empty()) {
+        hipEvent_t done = nullptr;
+        {
+            SideStream side;  // (falls back to the library stream when a second stream cannot be had)
+            if (int rc = reduce_and_embed()) return rc;
+            done = side.finish();
+        }
+        if (int rc = launch_tsqr_group(jobs, nc, n, cu_count(), done)) return rc;
+    } else {
+        if (int rc = reduce_and_embed()) return rc;
+        if (!jobs.empty())
+            if (int rc = launch_tsqr_group(jobs, nc, n, cu_count())) return rc;
+    }
     if (row_off == 0) {
         FIGH_HIP(hipMemsetAsync(stack, 0, tri, stream()));
         row_off = nc;
