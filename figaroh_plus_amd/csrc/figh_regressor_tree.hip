@@ -54,10 +54,13 @@
 
 namespace figh {
 
-enum : int32_t { OP_RESET = 0, OP_STEP = 1, OP_EMIT = 2, OP_ZERO = 3, OP_TX40 = 4, OP_FETCH = 5 };
+enum : int32_t { OP_RESET = 0, OP_STEP = 1, OP_EMIT = 2, OP_ZERO = 3, OP_TX40 = 4, OP_FETCH = 5, OP_RESTORE = 6 };
 // STEP flags (field b): bit 0 = the row's joint (J starts here), bits 4..6 = dof inside the joint (free-flyer),
 // bits 8.. = FETCH slot
-enum : int32_t { STEP_JSTART = 1 };
+// STEP_SAVE (free-flyer walk, force-compact W): the state behind this step is kept (one copy) -- the joint has several children, and OP_RESTORE
+// brings the walk back to it for the next child instead of a RESET and the steps down from the root again (human model: 57 -> 45
+// forward steps per sample, K1' 26.5 -> 25.4 ms)
+enum : int32_t { STEP_JSTART = 1, STEP_SAVE = 2 };
 // EMIT flags (field c)
 enum : int32_t { EMIT_INERT = 1, EMIT_EXTRA = 2, EMIT_OWN = 4, EMIT_FLUSH = 8, EMIT_NOSTORE = 16 };
 // joints per FETCH group (at most five: the payload fields of an op).  The free-flyer walk (one EMIT per STEP, state in ~250 registers
@@ -262,6 +265,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FC ? 1 : 2))
 #pragma unroll
             for (int d = 0; d < 3; ++d) Jl[s][d] = Ja[s][d] = 0.0;
         int jmask = 0;
+        // the state kept at a branch joint (STEP_SAVE / OP_RESTORE; the force-compact free-flyer walk only: at one wave per SIMD
+        // the copy lives in AGPRs -- the walks that run at two waves per SIMD spill for it or drop to one: TIAGo K1' 2.43 -> 2.90 ms,
+        // human link-compact 5.50 -> 6.35 .. 6.96 ms, same-box A/B with tools/var_run.sh / tools/k1_layout_ab.py)
+        double sV[6], sA[6], sRc[9], sPc[3];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) sV[d] = sA[d] = 0.0;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) sRc[d] = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sPc[d] = 0.0;
         // inputs of the coming single-dof joints (FETCH): q (cos q for a continuous joint), sin q, qd, qdd
         constexpr int kFetch = fetch_group(EXTFF);
         double sq0[kFetch], sq1[kFetch], sqd[kFetch], sqdd[kFetch];
@@ -403,6 +416,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FC ? 1 : 2))
                                 }
                             }
                         jmask = (jmask & ((1 << oc) - 1)) | (1 << oc);  // (deeper slots belong to a branch that was left)
+                    }
+                }
+                if constexpr (FC) {
+                    if (ob & STEP_SAVE) {
+#pragma unroll
+                        for (int d = 0; d < 6; ++d) {
+                            sV[d] = V[d];
+                            sA[d] = A[d];
+                        }
+#pragma unroll
+                        for (int d = 0; d < 9; ++d) sRc[d] = Rc[d];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) sPc[d] = pc[d];
                     }
                 }
                 // A STEP that is followed by the EMIT of its link runs it in the SAME iteration: every trip through the loop
@@ -597,6 +623,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FC ? 1 : 2))
                 for (int d = 0; d < 9; ++d) Rc[d] = (d % 4 == 0) ? 1.0 : 0.0;
                 pc[0] = pc[1] = pc[2] = 0.0;
                 jmask = 0;
+            } else if (FC && op == OP_RESTORE) {
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                    V[d] = sV[d];
+                    A[d] = sA[d];
+                }
+#pragma unroll
+                for (int d = 0; d < 9; ++d) Rc[d] = sRc[d];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) pc[d] = sPc[d];
             } else if (op == OP_TX40) {  // (regressor.py:198-227, fused): columns 14 nl .. + 2 on the six joint rows
                 if constexpr (STORE) {
                     if (lane < nvalid) {
@@ -660,6 +696,38 @@ struct TapeBuilder {
         for (int j = k; j > 0; j = h.parents[j]) p.insert(p.begin(), j);
         return p;
     }
+    // Which joints of the walk over the subtree of t keep the state behind their step (STEP_SAVE): there is ONE copy, so no two of
+    // them may lie on one root path; a joint with c children at depth d (d + 1 steps from the root) saves (c - 1)(d + 1)
+    // steps.  best(j) = max(own gain, sum over the children): the classic independent-set-on-paths recursion.
+    std::vector<char> choose_saves(int t, int end) const {
+        const int n = h.njoints;
+        std::vector<long> gain(n, 0), best(n, 0);
+        std::vector<int> nchild(n, 0);
+        for (int k = t + 1; k < end; ++k) ++nchild[h.parents[k]];
+        for (int j = end - 1; j >= t; --j) {
+            gain[j] = nchild[j] > 1 ? (long)(nchild[j] - 1) * (long)path_to(j).size() : 0;
+            long below = 0;
+            for (int k = j + 1; k < end; ++k)
+                if (h.parents[k] == j) below += best[k];
+            best[j] = gain[j] > below ? gain[j] : below;
+        }
+        std::vector<char> save(n, 0);
+        std::vector<int> todo = {t};
+        while (!todo.empty()) {
+            const int j = todo.back();
+            todo.pop_back();
+            long below = 0;
+            for (int k = j + 1; k < end; ++k)
+                if (h.parents[k] == j) below += best[k];
+            if (gain[j] > 0 && gain[j] >= below) {
+                save[j] = 1;
+                continue;
+            }
+            for (int k = j + 1; k < end; ++k)
+                if (h.parents[k] == j) todo.push_back(k);
+        }
+        return save;
+    }
     int subtree_end(int j) const {  // joints j .. end-1 form the subtree of j (depth-first numbering)
         int e = j + 1;
         while (e < h.njoints) {
@@ -719,12 +787,17 @@ std::vector<TapeOp> build_tape_extff(const DevModel &h, int flags, int ft_mask, 
         zero_from = -1;
     };
     T.push(OP_RESET);
+    const std::vector<char> save = force_compact ? T.choose_saves(1, h.njoints) : std::vector<char>(h.njoints, 0);
     for (int b = 1; b < h.njoints; ++b) {
         if (h.parents[b] != prev) {
-            T.push(OP_RESET);
-            for (int k : T.path_to(h.parents[b])) T.push(OP_STEP, k, k == 1 ? STEP_JSTART : 0);
+            if (save[h.parents[b]]) {
+                T.push(OP_RESTORE);
+            } else {
+                T.push(OP_RESET);
+                for (int k : T.path_to(h.parents[b])) T.push(OP_STEP, k, (k == 1 ? STEP_JSTART : 0) | (save[k] ? STEP_SAVE : 0));
+            }
         }
-        T.push(OP_STEP, b, b == 1 ? STEP_JSTART : 0);
+        T.push(OP_STEP, b, (b == 1 ? STEP_JSTART : 0) | (save[b] ? STEP_SAVE : 0));
         prev = b;
         const int inert = h.body_mask[b] ? (ft_mask & 63) : 0;
         if (inert || extras) {
