@@ -162,9 +162,14 @@ struct WyPairStack {  // one stack to reduce to one triangle
     double *out;
 };
 int reduce_wide_stacks(std::vector<WyPairStack> &stacks);
-// (before_embed: an event the stream waits for in front of the embedding launch -- the only launch that writes outside the
-// group's own workspaces)
-int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus, hipEvent_t before_embed = nullptr);
+// (later: the embedding launch -- the only launch that writes outside the group's own workspaces -- is not queued but
+// described there, for launch_tsqr_group_embed to queue once what it must follow has been queued)
+struct GroupEmbed {
+    const void *jobs = nullptr;
+    int njobs = 0, ncfull = 0, nfull = 0;
+};
+int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus, GroupEmbed *later = nullptr);
+int launch_tsqr_group_embed(const GroupEmbed &e);
 // figh_linalg.hip: stack of `count` compact nc x nc triangles -> one; tol_qr >= 0: + rank decision and regrouped rows
 // ((nc + 1) x nc doubles, layout in figh.h, figh_tsqr_selected), else the plain triangle
 int tsqr_reduce_stack(const double *d_Rs, long count, int nc, int n_free, double tol_qr, double *d_out);

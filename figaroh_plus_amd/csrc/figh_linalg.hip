@@ -1068,6 +1068,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     size_t wide_at = 0;
     std::vector<WyPairStack> wide;
     struct Embed {
+        int block;
         const double *R;
         int ncj, nj;
         const int *pos;
@@ -1082,12 +1083,15 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     int narrow = 0;
     for (int j = 0; j < nblocks; ++j) narrow += (h_counts[j] >= 1 && h_counts[j] + (d_tau ? 1 : 0) <= 64) ? 1 : 0;
     const bool grouped = narrow >= 4 && rows_b >= 64 * 64;
-    // With a grouped launch behind them, the merge levels of the other blocks -- latency-bound chains of small launches, 2.4 ms
-    // of TIAGo's 12.3 ms step -- run on the side stream WHILE the library stream runs the grouped level 0 (throughput-bound,
-    // 1.6 ms): every such block keeps its level-0 triangles (its own region instead of the shared tri_b) until all level-0
-    // launches are queued, then the side stream reduces and embeds them; the grouped embedding -- the only launch of the group
-    // that writes into the stack -- waits for the side work (a per-block embedding zero-fills nc rows from its offset).
-    const bool overlap = grouped;
+    // With a grouped launch in the pass, the merge levels -- latency-bound chains of small launches, 2.4 ms of TIAGo's 12.3 ms
+    // step when they ran one after the other behind all the level-0 launches -- are spread over two streams: the level-0
+    // launches of the WIDE blocks go first, and their merge levels (reduce_wide_stacks) run on the high-priority side stream
+    // from then on, beside the library stream's level-0 launches of the mid blocks (65 .. 80 columns) and of the group (little
+    // of them gets in while those fill the chip: a 512-thread workgroup does not find its eight wave slots between one-wave
+    // workgroups) and beside the mid blocks' and the group's own merge levels behind them.  A mid block keeps its level-0
+    // triangles in its own region instead of the shared tri_b.  All embeddings come last, in block order (a per-block embedding
+    // zero-fills nc rows from its offset, the grouped one writes exactly the group's rows).
+    const bool overlap = true;  // (also without a group: the side stream's merges run beside the other blocks' level 0)
     struct MidStack {
         double *tri;
         long cnt;
@@ -1103,97 +1107,102 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         }
     double *mid_tri = mid_doubles ? static_cast<double *>(workspace(sizeof(double) * mid_doubles, 38)) : nullptr;
     if (mid_doubles && !mid_tri) return FIGH_ERR_ALLOC;
+    // what every block is and where its rows of the stack / entries of the column lists start
+    enum { SKIP, JOB, WIDE, MID, PLAIN };
+    int kind[kMaxJoints];
+    long row_at[kMaxJoints], off_at[kMaxJoints];
     long row_off = 0, off = 0;
     for (int j = 0; j < nblocks; ++j) {
         const int nj = h_counts[j], ncj = nj + (d_tau ? 1 : 0);
-        // (block-compact W, FIGH_FLAG_COMPACT_BLOCKS: every row block is a matrix of its own; d_cols are then columns of it)
-        const double *Wj = h_block_off ? d_W + h_block_off[j] : d_W + (int64_t)j * rows_b * ldw;
-        const int64_t ldj = h_block_ld ? h_block_ld[j] : ldw;
-        const double *tj = d_tau ? d_tau + (int64_t)j * rows_b : nullptr;
-        if (nj < 0 || (nj == 0 && !d_tau)) continue;  // (an inactive row block / nothing of this block is kept)
-        if (grouped && nj >= 1 && ncj <= 64) {
-            Tsqr2Job J{};
-            J.W = Wj;
-            J.tau = tj;
-            J.col_idx = d_cols + off;
-            J.pos = d_pos + off;
-            J.out = stack + (size_t)row_off * nc;
-            J.rows = rows_b;
-            J.ldw = ldj;
-            J.n = nj;
-            J.nc = ncj;
-            jobs.push_back(J);
-            row_off += ncj;
-            off += nj;
+        row_at[j] = row_off;
+        off_at[j] = off;
+        if (nj < 0 || (nj == 0 && !d_tau)) {  // (an inactive row block / nothing of this block is kept)
+            kind[j] = SKIP;
             continue;
         }
-        int64_t cnt = 0;
-        double *Rb = Rb_all + (size_t)j * nmax * nmax;
-        if (nj > 0 && ncj > 80) {
-            const int64_t cap_j = figh_tsqr_level0_capacity(ncj);
-            double *tri_j = wide_tri + wide_at;
-            wide_at += (size_t)ncj * ncj * (size_t)cap_j;
-            if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_j, cap_j, &cnt, nullptr))
-                return rc;
-            wide.push_back({tri_j, (long)cnt, ncj, Rb});
-            embeds.push_back({Rb, ncj, nj, d_pos + off, stack + (size_t)row_off * nc});
-            row_off += ncj;
-            off += nj;
-            continue;
-        }
-        if (overlap && nj > 0 && ncj > 64) {  // (65 .. 80 columns: the register-tile kernel; reduced on the side stream)
-            const int64_t cap_j = figh_tsqr_level0_capacity(ncj);
-            double *tri_j = mid_tri + mid_at;
-            mid_at += (size_t)ncj * ncj * (size_t)cap_j;
-            if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_j, cap_j, &cnt, nullptr))
-                return rc;
-            mids.push_back({tri_j, (long)cnt, ncj, Rb});
-            embeds.push_back({Rb, ncj, nj, d_pos + off, stack + (size_t)row_off * nc});
-            row_off += ncj;
-            off += nj;
-            continue;
-        }
-        if (nj > 0) {
-            if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, d_cols + off, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr))
-                return rc;
-        } else {
-            // (only tau in this block: its norm still counts) a 1 x 1 "matrix", the tau rows alone, through the same
-            // kernel with tau as its only column
-            if (int rc = figh_tsqr_level0(tj, rows_b, 1, nullptr, 1, nullptr, nullptr, 0, tri_b, cap_b, &cnt, nullptr)) return rc;
-        }
-        if (cnt == 1) FIGH_HIP(hipMemcpyAsync(Rb, tri_b, sizeof(double) * (size_t)ncj * ncj, hipMemcpyDeviceToDevice, stream()));
-        else if (int rc = tsqr_reduce(tri_b, cnt, ncj, Rb)) return rc;
-        // (the embedding zero-fills nc rows from its offset and writes the block's ncj rows: the rows behind them belong to
-        // the next block, whose own embedding follows in stream order; the buffer ends nc rows behind the last block)
-        embeds.push_back({Rb, ncj, nj, d_pos + off, stack + (size_t)row_off * nc});
+        kind[j] = (grouped && nj >= 1 && ncj <= 64) ? JOB : (nj > 0 && ncj > 80) ? WIDE : (overlap && nj > 0 && ncj > 64) ? MID : PLAIN;
         row_off += ncj;
         off += nj;
     }
-    auto reduce_and_embed = [&]() -> int {
-        for (const MidStack &ms : mids) {
-            if (ms.cnt == 1)
-                FIGH_HIP(hipMemcpyAsync(ms.R, ms.tri, sizeof(double) * (size_t)ms.ncj * ms.ncj, hipMemcpyDeviceToDevice, stream()));
-            else if (int rc = tsqr_reduce(ms.tri, ms.cnt, ms.ncj, ms.R))
+    SideStream *side = nullptr;
+    hipEvent_t wide_done = nullptr;
+    struct SideGuard {  // (an error return leaves the side stream joined)
+        SideStream *&s;
+        ~SideGuard() { delete s; }
+    } guard{side};
+    for (int phase = 0; phase < 2; ++phase) {  // the wide blocks first
+        for (int j = 0; j < nblocks; ++j) {
+            if (kind[j] == SKIP || (kind[j] == WIDE) != (phase == 0)) continue;
+            const int nj = h_counts[j], ncj = nj + (d_tau ? 1 : 0);
+            // (block-compact W, FIGH_FLAG_COMPACT_BLOCKS: every row block is a matrix of its own; d_cols are then columns of it)
+            const double *Wj = h_block_off ? d_W + h_block_off[j] : d_W + (int64_t)j * rows_b * ldw;
+            const int64_t ldj = h_block_ld ? h_block_ld[j] : ldw;
+            const double *tj = d_tau ? d_tau + (int64_t)j * rows_b : nullptr;
+            const int32_t *cols_j = d_cols + off_at[j], *pos_j = d_pos + off_at[j];
+            double *out_j = stack + (size_t)row_at[j] * nc;
+            if (kind[j] == JOB) {
+                Tsqr2Job J{};
+                J.W = Wj;
+                J.tau = tj;
+                J.col_idx = cols_j;
+                J.pos = pos_j;
+                J.out = out_j;
+                J.rows = rows_b;
+                J.ldw = ldj;
+                J.n = nj;
+                J.nc = ncj;
+                jobs.push_back(J);
+                continue;
+            }
+            int64_t cnt = 0;
+            double *Rb = Rb_all + (size_t)j * nmax * nmax;
+            if (kind[j] == WIDE || kind[j] == MID) {
+                const int64_t cap_j = figh_tsqr_level0_capacity(ncj);
+                double *tri_j = kind[j] == WIDE ? wide_tri + wide_at : mid_tri + mid_at;
+                (kind[j] == WIDE ? wide_at : mid_at) += (size_t)ncj * ncj * (size_t)cap_j;
+                if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, cols_j, nj, tj, nullptr, 0, tri_j, cap_j, &cnt, nullptr)) return rc;
+                if (kind[j] == WIDE) wide.push_back({tri_j, (long)cnt, ncj, Rb});
+                else mids.push_back({tri_j, (long)cnt, ncj, Rb});
+                embeds.push_back({j, Rb, ncj, nj, pos_j, out_j});
+                continue;
+            }
+            if (nj > 0) {
+                if (int rc = figh_tsqr_level0(Wj, rows_b, ldj, cols_j, nj, tj, nullptr, 0, tri_b, cap_b, &cnt, nullptr)) return rc;
+            } else {
+                // (only tau in this block: its norm still counts) a 1 x 1 "matrix", the tau rows alone, through the same
+                // kernel with tau as its only column
+                if (int rc = figh_tsqr_level0(tj, rows_b, 1, nullptr, 1, nullptr, nullptr, 0, tri_b, cap_b, &cnt, nullptr)) return rc;
+            }
+            if (cnt == 1) FIGH_HIP(hipMemcpyAsync(Rb, tri_b, sizeof(double) * (size_t)ncj * ncj, hipMemcpyDeviceToDevice, stream()));
+            else if (int rc = tsqr_reduce(tri_b, cnt, ncj, Rb)) return rc;
+            embeds.push_back({j, Rb, ncj, nj, pos_j, out_j});
+        }
+        if (phase == 0 && !wide.empty()) {
+            if (overlap) {
+                side = new SideStream();  // (falls back to the library stream when a second stream cannot be had)
+                if (int rc = reduce_wide_stacks(wide)) return rc;
+                wide_done = side->finish();
+            } else if (int rc = reduce_wide_stacks(wide)) {
                 return rc;
+            }
         }
-        if (int rc = reduce_wide_stacks(wide)) return rc;
-        for (const Embed &e : embeds)
-            if (int rc = embed_force_triangle(e.R, e.ncj, e.nj, e.pos, nc, n, e.out)) return rc;
-        return FIGH_OK;
-    };
-    if (overlap && !jobs.empty() && !embeds.empty()) {
-        hipEvent_t done = nullptr;
-        {
-            SideStream side;  // (falls back to the library stream when a second stream cannot be had)
-            if (int rc = reduce_and_embed()) return rc;
-            done = side.finish();
-        }
-        if (int rc = launch_tsqr_group(jobs, nc, n, cu_count(), done)) return rc;
-    } else {
-        if (int rc = reduce_and_embed()) return rc;
-        if (!jobs.empty())
-            if (int rc = launch_tsqr_group(jobs, nc, n, cu_count())) return rc;
     }
+    GroupEmbed group_embed;
+    if (!jobs.empty())
+        if (int rc = launch_tsqr_group(jobs, nc, n, cu_count(), &group_embed)) return rc;
+    for (const MidStack &ms : mids) {
+        if (ms.cnt == 1)
+            FIGH_HIP(hipMemcpyAsync(ms.R, ms.tri, sizeof(double) * (size_t)ms.ncj * ms.ncj, hipMemcpyDeviceToDevice, stream()));
+        else if (int rc = tsqr_reduce(ms.tri, ms.cnt, ms.ncj, ms.R))
+            return rc;
+    }
+    stream_wait(wide_done);
+    // (the embedding zero-fills nc rows from its offset and writes the block's ncj rows: the rows behind them belong to the next
+    // block, whose own embedding follows in stream order; the buffer ends nc rows behind the last block)
+    std::sort(embeds.begin(), embeds.end(), [](const Embed &x, const Embed &y) { return x.block < y.block; });
+    for (const Embed &e : embeds)
+        if (int rc = embed_force_triangle(e.R, e.ncj, e.nj, e.pos, nc, n, e.out)) return rc;
+    if (int rc = launch_tsqr_group_embed(group_embed)) return rc;
     if (row_off == 0) {
         FIGH_HIP(hipMemsetAsync(stack, 0, tri, stream()));
         row_off = nc;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void embed_group_kernel(const Tsqr2Job *__rest
 
 // Host side: the jobs come with W, rows, ldw, col_idx, pos, tau, n, nc, out filled in by the caller; the rest is planned
 // here.  All jobs have nc <= 64 and at least 64 rows.
-int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus, hipEvent_t before_embed) {
+int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cus, GroupEmbed *later) {
     const int njobs = (int)jobs.size();
     if (njobs == 0) return FIGH_OK;
     // waves per job: as many as its tiles allow (a leaf much taller than wide), at most 512 -- three merge levels of 512
@@ -204,9 +204,23 @@ int launch_tsqr_group(std::vector<Tsqr2Job> &jobs, int ncfull, int nfull, int cu
             if (!job_of_wg[l].empty())
                 hipLaunchKernelGGL(tsqr_coop_group_kernel, dim3((unsigned)job_of_wg[l].size()), dim3(512), 0, stream(), d_jobs,
                                    d_maps + off_l[l], l);
-        stream_wait(before_embed);
-        hipLaunchKernelGGL(embed_group_kernel, dim3((unsigned)njobs), dim3(256), 0, stream(), d_jobs, ncfull, nfull);
+        if (later) {
+            later->jobs = d_jobs;
+            later->njobs = njobs;
+            later->ncfull = ncfull;
+            later->nfull = nfull;
+        } else {
+            hipLaunchKernelGGL(embed_group_kernel, dim3((unsigned)njobs), dim3(256), 0, stream(), d_jobs, ncfull, nfull);
+        }
     }
+    FIGH_HIP(hipGetLastError());
+    return FIGH_OK;
+}
+
+int launch_tsqr_group_embed(const GroupEmbed &e) {
+    if (e.njobs == 0) return FIGH_OK;
+    hipLaunchKernelGGL(embed_group_kernel, dim3((unsigned)e.njobs), dim3(256), 0, stream(),
+                       static_cast<const Tsqr2Job *>(e.jobs), e.ncfull, e.nfull);
     FIGH_HIP(hipGetLastError());
     return FIGH_OK;
 }
