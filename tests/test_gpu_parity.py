@@ -2489,14 +2489,20 @@ def test_tiago_real_data_known_answers_hip(lib):
     assert np.abs(std - csvv[:, 1] / 100).max() <= 0.011
 
 
-def _synthetic_tree(parents, seed=5, massless=()):
-    """A fixed-base tree of single-dof joints (revolute / prismatic / continuous at random, random unit axes, placements and
-    inertias; ``massless`` links carry no body) from a parent list in depth-first numbering: parents[k - 1] = parent of joint k."""
+def _synthetic_tree(parents, seed=5, massless=(), freeflyer=False):
+    """A tree of single-dof joints (revolute / prismatic / continuous at random, random unit axes, placements and inertias;
+    ``massless`` links carry no body) from a parent list in depth-first numbering: parents[k - 1] = parent of joint k.
+    ``freeflyer``: joint 1 is a free-flyer root with a body (parents[0] is ignored), the model of an external-wrench regressor."""
     from figaroh_plus_amd.model import Inertia, Model, SE3
     from figaroh_plus_amd.tools.robot import Robot
     rng = np.random.default_rng(seed)
     model = Model("tree%d" % len(parents))
     for k, par in enumerate(parents, start=1):
+        if freeflyer and k == 1:
+            model.add_joint(0, 3, None, SE3(), "root_joint")
+            A = rng.standard_normal((3, 3))
+            model.append_body(1, Inertia(rng.uniform(2.0, 5.0), rng.uniform(-0.1, 0.1, 3), 0.02 * (A @ A.T) + 0.01 * np.eye(3)), SE3())
+            continue
         axis = rng.standard_normal(3)
         axis /= np.linalg.norm(axis)
         w = rng.standard_normal(3)
@@ -2511,7 +2517,7 @@ def _synthetic_tree(parents, seed=5, massless=()):
             A = rng.standard_normal((3, 3))
             model.append_body(k, Inertia(rng.uniform(0.5, 3.0), rng.uniform(-0.1, 0.1, 3), 0.01 * (A @ A.T) + 0.005 * np.eye(3)),
                               SE3())
-    return Robot("synthetic", None, isFext=False, _model=model)
+    return Robot("synthetic", None, isFext=freeflyer, _model=model)
 
 
 _TREES = {
@@ -2600,3 +2606,59 @@ def test_tree_walks_random_trees_against_oracle(lib, oracle_lib, shape, flags):
         Wk = W_ref[:, keep] if blocks is None else np.vstack([W_ref[b * N:(b + 1) * N, keep] for b in blocks])
         res = Wk @ np.linalg.lstsq(Wk, t, rcond=None)[0] - t
         assert abs(out["residual_norm"] - np.linalg.norm(res)) <= 1e-8 * max(1.0, np.linalg.norm(t))
+
+
+@pytest.mark.parametrize("shape", ["binary15", "caterpillar", "star", "fork"])
+def test_freeflyer_walk_state_copy_on_random_trees(lib, oracle_lib, shape):
+    """The free-flyer walk of the tape kernel with the state copy at branch joints (STEP_SAVE / OP_RESTORE: the force-compact
+    instantiation, the pipeline's default layout for an external-wrench regressor) on random floating-base trees with nested
+    and sibling branch joints: column norms against the oracle's W, and every result of the pass equal to that of the
+    link-padded layout (the instantiation without the copy: every branch is re-entered from the root), whose W is compared
+    with the oracle entry by entry."""
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    parents = [0] + [p + 1 for p in _TREES[shape]]  # the tree hangs off the free-flyer root
+    massless = (6, 9) if shape in ("fork", "caterpillar") else ()
+    robot = _synthetic_tree(parents, seed=3 + len(parents), massless=massless, freeflyer=True)
+    m = robot.model
+    param = dict(is_joint_torques=False, is_external_wrench=True, has_friction=False, has_actuator_inertia=False,
+                 has_joint_offset=False, force_torque=["All"])
+    N = 64 * 40 + 23  # (the force / torque split of the force-compact layout wants 32 rows per kept column)
+    rng = np.random.default_rng(11 + len(parents))
+    q = np.zeros((N, m.nq))
+    quat = rng.standard_normal((N, 4))
+    q[:, :3], q[:, 3:7] = rng.uniform(-1, 1, (N, 3)), quat / np.linalg.norm(quat, axis=1)[:, None]
+    for j in m.joints[2:]:
+        if j.nq == 2:
+            th = rng.uniform(-3, 3, N)
+            q[:, j.idx_q], q[:, j.idx_q + 1] = np.cos(th), np.sin(th)
+        else:
+            q[:, j.idx_q] = rng.uniform(-2, 2, N)
+    v, a = rng.uniform(-2, 2, (N, m.nv)), rng.uniform(-3, 3, (N, m.nv))
+    om = oracle_lib.OracleModel(m.to_flat())
+    mode, fl, ft = oracle_lib.param_flags(param, False)
+    W_ref = om.build_regressor_basic(q, v, a, mode, fl, ft)
+    nl = m.njoints - 1
+    assert W_ref.shape == (6 * N, 14 * nl)
+    scale = np.abs(W_ref).max()
+    params_std = robot.get_standard_parameters(param)
+    tau = W_ref @ np.array(list(params_std.values()), dtype=float) + 1e-3 * rng.standard_normal(len(W_ref))
+    ref_sq = (W_ref * W_ref).sum(axis=0)
+    outs = {}
+    for layout in ("link-padded", "dense"):
+        pipe = IdentificationPipeline(robot, param, params_std=params_std, w_layout=layout)
+        pipe.set_samples(q, v, a, tau)
+        pipe.run()
+        outs[layout] = pipe.run()
+        assert np.abs(outs[layout]["col_norm"] - ref_sq).max() <= 1e-12 * ref_sq.max()
+        if layout == "link-padded":
+            assert not getattr(pipe, "_force_ld", 0)
+            padded = np.zeros((len(W_ref), 16 * nl))
+            padded[:, (np.arange(14 * nl) // 14) * 16 + np.arange(14 * nl) % 14] = W_ref
+            assert np.abs(pipe.W.numpy() - padded).max() <= 1e-12 * scale
+        else:
+            assert getattr(pipe, "_force_ld", 0) > 0  # (the instantiation with the state copy ran)
+    a_, b_ = outs["link-padded"], outs["dense"]
+    assert a_["idx_e"] == b_["idx_e"] and a_["idx_base"] == b_["idx_base"] and a_["params_base"] == b_["params_base"]
+    assert np.abs(a_["col_norm"] - b_["col_norm"]).max() <= 1e-13 * ref_sq.max()
+    assert abs(a_["residual_norm"] - b_["residual_norm"]) <= 1e-9 * max(1.0, a_["residual_norm"])
+    assert np.abs(a_["phi_ls"] - b_["phi_ls"]).max() <= 1e-6 * max(1.0, np.abs(a_["phi_ls"]).max())
