@@ -1124,12 +1124,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         row_off += ncj;
         off += nj;
     }
-    SideStream *side = nullptr;
     hipEvent_t wide_done = nullptr;
-    struct SideGuard {  // (an error return leaves the side stream joined)
-        SideStream *&s;
-        ~SideGuard() { delete s; }
-    } guard{side};
     for (int phase = 0; phase < 2; ++phase) {  // the wide blocks first
         for (int j = 0; j < nblocks; ++j) {
             if (kind[j] == SKIP || (kind[j] == WIDE) != (phase == 0)) continue;
@@ -1179,9 +1174,10 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
         }
         if (phase == 0 && !wide.empty()) {
             if (overlap) {
-                side = new SideStream();  // (falls back to the library stream when a second stream cannot be had)
+                SideStream side;  // (falls back to the library stream when a second stream cannot be had; an error return
+                                  // leaves the streams joined)
                 if (int rc = reduce_wide_stacks(wide)) return rc;
-                wide_done = side->finish();
+                wide_done = side.finish();
             } else if (int rc = reduce_wide_stacks(wide)) {
                 return rc;
             }
