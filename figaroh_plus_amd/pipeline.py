@@ -549,7 +549,8 @@ class IdentificationPipeline:
             _lib.check(lib.figh_memcpy_h2d(buf.ptr, kept.ctypes.data, kept.nbytes))
             self._fused_kept = (kept_mask.copy(), buf, len(kept))
         rows_mine = W.rows if self.row_blocks is None else len(self.row_blocks) * self.N
-        return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, rows_mine * ex.world_size, strings)
+        return self._finish(rows_k, n, nc, params_r, idx_e, col_norm, with_tau, rows_mine * ex.world_size, strings,
+                            defer_beta=wls and with_tau)
 
     def forget(self):
         """Drop everything the pipeline has learnt from earlier passes (kept-column set, counts, per-block lists): the next
@@ -726,7 +727,8 @@ class IdentificationPipeline:
             d_one = self._sb("wls_one", (nb_par + 1) * (nb_par + 1))
             _lib.tsqr_merge(d_stack, count, nb_par + 1, d_one)
             d_Rw = d_one
-        if strings and "params_base" not in out:  # (the device is busy with the weighted factorisation meanwhile)
+        self._finish_beta(out)  # (the device is busy with the weighted factorisation meanwhile)
+        if strings and "params_base" not in out:
             params_r = out["params_r"]
             regroup = np.setdiff1d(np.arange(n), base).tolist()
             out["params_base"] = qrd._expressions([params_r[i] for i in base.tolist()], [params_r[i] for i in regroup],
@@ -741,6 +743,16 @@ class IdentificationPipeline:
             std = _relative_percent(np.sqrt(np.einsum("ij,ij->i", R_inv, R_inv)), phi)  # (phi_i == 0: inf, as in the script)
         out["phi_wls"], out["std_wls"], out["sigma2_joint"], out["wls_source"] = phi, std, sig2, source
         return out
+
+    def _finish_beta(self, out):
+        """The regrouping coefficients _finish left for later (``defer_beta``): beta = R1^-1 R2, rounded (qrdecomposition.py:244)."""
+        later = getattr(self, "_beta_later", None)
+        if later is None or out.get("beta") is not None:
+            return
+        R1, R2, _, _ = later
+        self._beta_later = None
+        with _single_threaded_blas(len(R1)):
+            out["beta"] = np.around(_solve_upper(R1, np.asfortranarray(R2)), 6)
 
     def _block_lists(self, ncols, stride):
         """(mask, counts, d_cols, d_pos) for figh_tsqr_selected_blocks, from the kept mask this pass expects: row block j
@@ -864,7 +876,7 @@ class IdentificationPipeline:
         _lib.check(lib.figh_memcpy_d2h(host.ctypes.data, pack.ptr, host.nbytes))
         return self._finish(host.reshape(nc + 1, nc), n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings)
 
-    def _finish(self, rows_k, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings):
+    def _finish(self, rows_k, n, nc, params_r, idx_e, col_norm, with_tau, total_rows, strings, defer_beta=False):
         """Host tail on the n x n numbers the device returns (qrdecomposition.py:215-266): ``rows_k`` ((nc + 1) x nc) holds,
         in the original column order, the rows of the regrouped factorisation qr([W1 W2 tau]) at the base columns and, in
         its last row, the diagonal of the plain factorisation (include/figh.h, figh_tsqr_selected)."""
@@ -887,6 +899,12 @@ class IdentificationPipeline:
                     raise np.linalg.LinAlgError("Singular matrix")
                 beta = np.around(R1_inv @ R2, 6)
                 phi_ls = R1_inv @ z if with_tau else None
+            elif defer_beta:
+                # the weighted solve comes next and only needs phi: the regrouping coefficients (the larger solve: 55 right-hand
+                # sides for TIAGo) wait until the weighted factorisation has been launched (_finish_beta, called by _wls)
+                phi_ls = np.ascontiguousarray(_solve_upper(R1, np.asfortranarray(z.reshape(-1, 1)))[:, 0])
+                beta = None
+                self._beta_later = (np.ascontiguousarray(R1), R2, idx_base, idx_regroup)
             else:
                 # wide problems (TALOS: 234 base columns, 96 regrouped): one triangular solve of [R2 z] is a third of the
                 # flops of inverse + products (host tail 2.0 -> 1.2 ms)
@@ -898,7 +916,7 @@ class IdentificationPipeline:
             "idx_e": idx_e, "params_r": params_r, "idx_base": idx_base, "beta": beta,
             "col_norm": col_norm, "absdiagR": diag[:n].copy(), "rows": total_rows,
         }
-        if strings:
+        if strings and beta is not None:
             out["params_base"] = qrd._expressions([params_r[i] for i in idx_base],
                                                   [params_r[i] for i in idx_regroup], beta)
         if with_tau:
