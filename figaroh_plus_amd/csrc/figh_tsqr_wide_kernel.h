@@ -880,6 +880,7 @@ struct WyConfig {
     // (three by LDS instead of two) carry more chains at a time
     if (nch <= 6) return {2, 3, 6, 2, 0};
     if (nch <= 8) return {2, 4, 5, 2, 0};  // 97 .. 128 columns (TIAGo's torso block): two waves x four chunks, 80-row tiles
+    if (nch <= 10) return {2, 5, 4, 2, 0};  // 129 .. 160 columns (TALOS' force rows): two waves x five chunks, 64-row tiles
     if (nch <= 12) return {4, 3, 6, 2, 0};
     if (nch <= 16) return {4, 4, 5, 2, 0};
     if (nch <= 20) return {4, 5, 4, 2, 0};
@@ -902,6 +903,7 @@ bool wy_dispatch(const WyConfig cfg, F &&f) {
 #define FIGH_WY_CASE(NW_, CPW_, NRC_, WPE_) FIGH_WY_CASE_L(NW_, CPW_, NRC_, WPE_, false)
     FIGH_WY_CASE(2, 3, 6, 2)
     FIGH_WY_CASE(2, 4, 5, 2)
+    FIGH_WY_CASE(2, 5, 4, 2)
     FIGH_WY_CASE(4, 3, 6, 2)
     FIGH_WY_CASE(4, 4, 5, 2)
     FIGH_WY_CASE(4, 5, 4, 2)
