@@ -1091,7 +1091,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     // workgroups) and beside the mid blocks' and the group's own merge levels behind them.  A mid block keeps its level-0
     // triangles in its own region instead of the shared tri_b.  All embeddings come last, in block order (a per-block embedding
     // zero-fills nc rows from its offset, the grouped one writes exactly the group's rows).
-    const bool overlap = true;  // (also without a group: the side stream's merges run beside the other blocks' level 0)
+    // (Also without a group: the side stream's merges then run beside the other blocks' level 0.)
     struct MidStack {
         double *tri;
         long cnt;
@@ -1100,11 +1100,10 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
     };
     std::vector<MidStack> mids;
     size_t mid_doubles = 0, mid_at = 0;
-    if (overlap)
-        for (int j = 0; j < nblocks; ++j) {
-            const int ncj = h_counts[j] + (d_tau ? 1 : 0);
-            if (h_counts[j] > 0 && ncj > 64 && ncj <= 80) mid_doubles += (size_t)ncj * ncj * (size_t)figh_tsqr_level0_capacity(ncj);
-        }
+    for (int j = 0; j < nblocks; ++j) {
+        const int ncj = h_counts[j] + (d_tau ? 1 : 0);
+        if (h_counts[j] > 0 && ncj > 64 && ncj <= 80) mid_doubles += (size_t)ncj * ncj * (size_t)figh_tsqr_level0_capacity(ncj);
+    }
     double *mid_tri = mid_doubles ? static_cast<double *>(workspace(sizeof(double) * mid_doubles, 38)) : nullptr;
     if (mid_doubles && !mid_tri) return FIGH_ERR_ALLOC;
     // what every block is and where its rows of the stack / entries of the column lists start
@@ -1120,7 +1119,7 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
             kind[j] = SKIP;
             continue;
         }
-        kind[j] = (grouped && nj >= 1 && ncj <= 64) ? JOB : (nj > 0 && ncj > 80) ? WIDE : (overlap && nj > 0 && ncj > 64) ? MID : PLAIN;
+        kind[j] = (grouped && nj >= 1 && ncj <= 64) ? JOB : (nj > 0 && ncj > 80) ? WIDE : (nj > 0 && ncj > 64) ? MID : PLAIN;
         row_off += ncj;
         off += nj;
     }
@@ -1173,14 +1172,10 @@ int figh_tsqr_selected_blocks(const double *d_W, int64_t rows, int64_t ldw, cons
             embeds.push_back({j, Rb, ncj, nj, pos_j, out_j});
         }
         if (phase == 0 && !wide.empty()) {
-            if (overlap) {
-                SideStream side;  // (falls back to the library stream when a second stream cannot be had; an error return
-                                  // leaves the streams joined)
-                if (int rc = reduce_wide_stacks(wide)) return rc;
-                wide_done = side.finish();
-            } else if (int rc = reduce_wide_stacks(wide)) {
-                return rc;
-            }
+            SideStream side;  // (falls back to the library stream when a second stream cannot be had; an error return leaves
+                              // the streams joined)
+            if (int rc = reduce_wide_stacks(wide)) return rc;
+            wide_done = side.finish();
         }
     }
     GroupEmbed group_embed;
