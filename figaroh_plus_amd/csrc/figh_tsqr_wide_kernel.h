@@ -881,7 +881,7 @@ struct WyConfig {
     if (nch <= 6) return {2, 3, 6, 2, 0};
     if (nch <= 8) return {2, 4, 5, 2, 0};  // 97 .. 128 columns (TIAGo's torso block): two waves x four chunks, 80-row tiles
     if (nch <= 10) return {2, 5, 4, 2, 0};  // 129 .. 160 columns (TALOS' force rows): two waves x five chunks, 64-row tiles
-    if (nch <= 12) return {4, 3, 6, 2, 0};
+    if (nch <= 12) return {4, 3, 6, 2, 0};  // (two waves x six chunks with 48-row tiles: human torque rows 71 -> 79 ms)
     if (nch <= 16) return {4, 4, 5, 2, 0};
     if (nch <= 20) return {4, 5, 4, 2, 0};
     if (nch == 21) return {4, 5, 4, 2, 1};  // TALOS (331 columns): 64-row tiles, chunk 20 in LDS
