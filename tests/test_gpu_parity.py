@@ -379,6 +379,83 @@ def _spot_rows_padded(pipe, g, oracle_lib, qva, rps, rng):
         assert not hostf[:, np.setdiff1d(np.arange(ldf), fcols)].any()
 
 
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("layout", ["dense", "block-compact"])
+def test_full_size_tiago_and_rank_crossing(lib, oracle_lib, layout):
+    """BASELINE configs[2] (TIAGo, fv/fs/Ia/off, 1e6 samples = 24e6 x 336) at full size (examples/tiago/identification.py:293-337,
+    qrdecomposition.py:208-221), plus the finding that comes with it: four structurally dependent pivots of the TIAGo
+    regressor are genuine tiny numbers that grow like sqrt(N) (6.3e-9 at 1e5 samples, 1.26e-8 at 4e5) and cross
+    TOL_QR = 1e-8, so the base-parameter count goes 179 -> 183 -> 185 with N -- in the REFERENCE too (np.linalg.qr of the same
+    rows).  Checked from OUTSIDE the HIP path: against LAPACK on the oracle's W at 1e5 samples (all pivots, identical index
+    set = the golden 179), against tests/golden/cfg3_tiago_large.json (oracle W + blocked LAPACK Householder TSQR,
+    oracle/pin_cfg3_large.py) at 4e5 and at the BASELINE size 1e6.  ``dense`` is the link-padded resident W (spot rows
+    against the oracle), ``block-compact`` the layout bench.py --config cfg3 runs."""
+    from conftest import Golden
+    from figaroh_plus_amd.pipeline import IdentificationPipeline
+    from figaroh_plus_amd.tools.randomdata import sample_inputs
+    rng = np.random.default_rng(11)
+
+    def tiago(N):
+        g = Golden("cfg3_tiago")
+        robot = g.robot()
+        qva = sample_inputs(robot.model, N, np.random.default_rng(5), 1.5, 2, 5)
+        pipe = IdentificationPipeline(robot, g.param, params_std=g.params_std(), coupling=g.coupling, w_layout=layout)
+        pipe.set_samples(*qva)
+        pipe.set_tau_from_parameters(g.phi_ref())
+        return g, pipe, qva
+
+    # (i) 1e5 samples: every |R_ii| against LAPACK on the oracle's matrix, base set = golden
+    g, pipe, qva = tiago(100_000)
+    out1 = pipe.run()
+    assert out1["idx_e"] == list(g["idx_e"]) and out1["idx_base"] == list(g["idx_base"])
+    assert out1["params_base"] == g.meta["params_base"]
+    W_ref = _oracle_W(g, oracle_lib, *qva)
+    keep = [i for i in range(W_ref.shape[1]) if i not in set(out1["idx_e"])]
+    d_ref = np.abs(np.diag(np.linalg.qr(W_ref[:, keep], mode="r")))
+    del W_ref
+    big = d_ref > 1e-8
+    # (raw pivots of an UNPIVOTED QR are only comparable up to the direction of the noise reflectors of the dependent
+    # columns in front of them -- SURVEY.md section 7 -- so: the decision exactly, the magnitudes loosely, and the four
+    # borderline pivots, which carry the finding, tightly)
+    assert [i for i in range(len(keep)) if big[i]] == out1["idx_base"]
+    assert np.abs(out1["absdiagR"][big] / d_ref[big] - 1.0).max() <= 1e-3
+    dep1 = np.sort(out1["absdiagR"][~big])[-4:]  # the four borderline pivots
+    assert np.abs(np.sort(d_ref[~big])[-4:] / dep1 - 1.0).max() <= 1e-4 and dep1.min() > 3e-9
+    del pipe
+    # (ii) 4e5 samples: the same four pivots have doubled (sqrt(4)) and crossed the tolerance; pinned file
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cfg3_tiago_large.json")) as f:
+        pinned = {(c["N"], c["seed"]): c for c in json.load(f)["cases"]}
+    g, pipe, _ = tiago(400_000)
+    out4 = pipe.run()
+    pin4 = pinned[(400_000, 5)]
+    assert out4["idx_e"] == pin4["idx_e"] == list(g["idx_e"]) and out4["idx_base"] == pin4["idx_base"]
+    assert len(out4["idx_base"]) == 183
+    for k, val in pin4["near_tolerance"].items():  # the pivots near TOL_QR themselves, on both sides of it
+        assert abs(out4["absdiagR"][int(k)] / val - 1.0) <= 1e-4
+    crossed = sorted(set(out4["idx_base"]) - set(out1["idx_base"]))
+    assert len(crossed) == 4 and set(out1["idx_base"]) <= set(out4["idx_base"])
+    ratio = np.sort(out4["absdiagR"][crossed]) / np.sort(dep1)
+    assert np.all((ratio > 1.7) & (ratio < 2.3)), ratio
+    del pipe
+    # (iii) the BASELINE size
+    g, pipe, qva = tiago(1_000_000)
+    out = pipe.run()
+    pin10 = pinned[(1_000_000, 5)]
+    assert out["idx_e"] == pin10["idx_e"] == list(g["idx_e"]) and out["rows"] == 24_000_000
+    assert out["idx_base"] == pin10["idx_base"] and len(out["idx_base"]) == 185  # (two more pivots have crossed)
+    for k, val in pin10["near_tolerance"].items():
+        assert abs(out["absdiagR"][int(k)] / val - 1.0) <= 1e-4
+    assert out["absdiagR"][out["idx_base"]].min() > 1e-8
+    kept = np.array([i for i in range(336) if i not in set(out["idx_e"])])
+    assert np.abs(out["absdiagR"][0] ** 2 - out["col_norm"][kept[0]]) <= 1e-10 * out["col_norm"][kept[0]]  # R_00^2 = ||w_0||^2
+    # phi_b reproduces the regrouped standard parameters of the 185-parameter base (tau = W phi_ref exactly): W_b phi = tau
+    assert out["residual_norm"] <= 1e-6 * np.sqrt(out["rows"])
+    if layout == "dense":
+        _spot_rows_padded(pipe, g, oracle_lib, qva, 24, rng)
+    else:
+        assert pipe.W.compact is not None and pipe.W.buf.size * 8 < 12e9
+
+
 @pytest.mark.timeout(900)
 def test_full_size_talos(lib, oracle_lib):
     """BASELINE configs[3] (TALOS floating base, external wrench, 4e6 samples = 24e6 x 462) on one GPU: the structural
@@ -1999,6 +2076,26 @@ def test_null_pivot_rule_never_changes_the_base_set(lib, cfg, sizes):
             near = base[off["absdiagR"][base] < 100 * TOL_QR]
             assert np.abs(on_["absdiagR"][near] - off["absdiagR"][near]).max(initial=0.0) <= 1e-3 * TOL_QR
             assert min(on_["absdiagR"][base].min(), off["absdiagR"][base].min()) > TOL_QR
+    if cfg == "cfg3_tiago":
+        # ... and from OUTSIDE the HIP path: the samples tests/golden/cfg3_tiago_large.json pins at 4e5 (oracle W reduced by a
+        # blocked LAPACK Householder TSQR, oracle/pin_cfg3_large.py), rule on AND off against the pinned index sets and the
+        # six near-tolerance pivots (four just above TOL_QR, two just below)
+        with open(os.path.join(os.path.dirname(__file__), "golden", "cfg3_tiago_large.json")) as f:
+            pin4 = {(c["N"], c["seed"]): c for c in json.load(f)["cases"]}[(400_000, 5)]
+        q, v, a = sample_inputs(robot.model, 400_000, np.random.default_rng(5), 1.5, 2, 5)
+        for on in (False, True):
+            pipe = IdentificationPipeline(robot, g.param, params_std=g.params_std(), coupling=g.coupling, w_layout=layout,
+                                          null_pivots=on)
+            pipe.set_samples(q, v, a)
+            pipe.set_tau_from_parameters(g.phi_ref())
+            out = pipe.run()
+            del pipe
+            assert out["idx_e"] == pin4["idx_e"] and out["idx_base"] == pin4["idx_base"], on
+            for k, val in pin4["near_tolerance"].items():
+                assert abs(out["absdiagR"][int(k)] / val - 1.0) <= 1e-4, (on, k)
+            # every other dependent pivot sits far below the tolerance, as in the LAPACK reduction
+            dep = np.setdiff1d(np.arange(len(out["absdiagR"])), out["idx_base"] + [int(k) for k in pin4["near_tolerance"]])
+            assert out["absdiagR"][dep].max() <= TOL_QR / 2
 
 
 @pytest.mark.parametrize("flags", [dict(has_friction=True), dict(has_actuator_inertia=True, has_joint_offset=True)])
