@@ -206,6 +206,12 @@ def main():
     ap.add_argument("--no-fuse", action="store_true",
                     help="cfg2: K1 and the level-0 TSQR as two launches (W written, then read back) instead of the fused "
                          "launch figh_regressor_tsqr_fused (default: fused from the second pass on; config.fused says which)")
+    ap.add_argument("--strong-config", default="cfg4", choices=["", "cfg3", "cfg4", "cfg5"],
+                    help="after the headline workload, a fixed-total-size (strong-scaling) measurement of this sharded BASELINE "
+                         "config on the same ranks, reported as `strong_scaling` in the same line (north_star: >= 6x strong "
+                         "scaling at 8 GPUs); '' = leave it out")
+    ap.add_argument("--strong-samples", type=int, default=None, help="total samples of that measurement (default: the config's)")
+    ap.add_argument("--strong-steps", type=int, default=5)
     ap.add_argument("--host-wait", default=None, choices=["spin", "block"],
                     help="how the host waits for the GPU: spin (default for one GPU) or block = interrupt-driven (default "
                          "for several ranks on a node: spinning ranks can exhaust a container's CPU quota)")
@@ -216,12 +222,14 @@ def main():
     if stray:
         raise SystemExit("bench.py refuses to run with FIGH_* variables set: %s" % ", ".join(stray))
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes one (it has not touched the GPU and never will) -- see spawn_ranks
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
 
     from figaroh_plus_amd import _lib
     from figaroh_plus_amd.dist import exchange_from_env, shard_range
@@ -243,332 +251,363 @@ def main():
         if world > 1:
             group.barrier()
 
-    fixture, model_name, n_config, chunk = CONFIGS[args.config]
-    if args.chunk_samples and args.config == "cfg5":
-        chunk = args.chunk_samples
-    scaling = args.scaling or ("weak" if args.config == "cfg2" else "strong")
-    with open(os.path.join(ROOT, "tests", "golden", fixture + ".json")) as f:
-        meta = json.load(f)
-    robot = Robot.from_flat(model_name)
-    param = meta["param"]
-    params_std = dict(zip(meta["names_std"], meta["phi_ref_raw"]))
-    if scaling == "weak":
-        N = args.samples or n_config          # per GPU
-        n_total = N * world
-    else:
-        n_total = args.samples or n_config    # sharded: contiguous sample ranges (dist.shard_range)
-        lo, hi = shard_range(n_total, rank, world)
-        N = hi - lo
-    rng = np.random.default_rng(20250410 + int(args.config[3]) + 1000 * rank)
-    if args.config == "cfg2":  # examples/ur10/identification.py:71-81
-        q, v, a = (rng.uniform(-6, 6, (N, 6)) for _ in range(3))
-    else:
-        q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
-    row_blocks = None
-    if args.active_joints:
-        if args.config != "cfg3":
-            raise SystemExit("--active-joints is the TIAGo script's variant (cfg3)")
-        names = ["torso_lift_joint"] + ["arm_%d_joint" % k for k in range(1, 8)]
-        row_blocks = [robot.model.joints[robot.model.getJointId(n)].idx_v for n in names]
-    pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
-                                  row_blocks=row_blocks,
-                                  chunk_samples=chunk, placement_trials=args.placement_trials,
-                                  structural_zeros=args.structural_zeros,
-                                  w_layout="dense" if args.w_layout == "dense" else "block-compact", fuse=not args.no_fuse,
-                                  null_pivots=not args.no_null_pivots)
-    _lib.synchronize()
-    t_h2d = time.perf_counter()
-    pipe.set_samples(q, v, a)
-    _lib.synchronize()
-    t_h2d = time.perf_counter() - t_h2d - 1e-3 * getattr(pipe, "repack_ms", 0.0)
-    input_bytes = q.nbytes + v.nbytes + a.nbytes
-    phi_ref = np.array([float(x) for x in meta["phi_ref_raw"]])
-    # cfg3 is quoted with a WLS solve (BASELINE configs[2]): measurement noise, or the per-joint variances are round-off
-    pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config in ("cfg2", "cfg3") else 0.0, seed=rank)
-    wls = args.config == "cfg3" and not args.no_wls
-    del q, v, a
-
-    out = None
-    # live HIP-event timing of the dominant kernels on the library stream (level 1: the event pair of K1 and of the TSQR
-    # level 0 is stamped by their own dispatch packets, hipExtLaunchKernelGGL -- no extra packets in the queue), switched
-    # on during warm-up already so that the event pool exists before the timed region
-    _lib.profile_enable(True, level=1)
-    for _ in range(args.warmup):
-        out = pipe.run(wls=wls)
-    _lib.profile_reset()
-    barrier()
-    step_times = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        out = pipe.run(wls=wls)  # returns when its results are on the host: the per-step clock needs no extra synchronisation
-        step_times.append(time.perf_counter() - ts)
-    barrier()
-    dt = time.perf_counter() - t0
-    _lib.profile_enable(False)
-    dt_rank = dt
-    if world > 1:
-        dt = max(group.all_gather_object(dt))
-
-    # sanity: the step produced the reference's structural result (cfg3 at 1e6 samples: four dependent pivots grow past
-    # TOL_QR like sqrt(N), LAPACK agrees -- DESIGN.md section 4 -- so only the eliminated columns are compared there)
-    ok = out["idx_e"] == [int(x) for x in np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))["idx_e"]]
-    if args.config != "cfg3":
-        ok = ok and out["idx_base"] == meta_idx(meta) and out["params_base"] == meta["params_base"]
-    elif world == 1 and N == 1_000_000 and not args.active_joints:
-        # cfg3 at the BASELINE size: the index set a LAPACK Householder TSQR of the oracle's W keeps for THESE samples
-        # (tests/golden/cfg3_tiago_large.json, oracle/pin_cfg3_large.py: 185 base parameters -- six pivots of the golden's
-        # dependent columns have grown past TOL_QR like sqrt(N))
-        with open(os.path.join(ROOT, "tests", "golden", "cfg3_tiago_large.json")) as f:
-            pin = next(c for c in json.load(f)["cases"] if c["N"] == N and c["seed"] == 20250410 + 3)
-        ok = ok and out["idx_base"] == pin["idx_base"]
-    n_kept = len(out["params_r"])
-    kern = {}
-    k1_name = "regressor_chain" if args.config == "cfg2" else "regressor_tree"
-    for name in (k1_name, "tsqr", "fused_chain_tsqr"):
-        cnt, ms = _lib.profile_get(name)
-        if cnt:
-            kern[name] = {"launches": cnt, "avg_ms": ms / cnt}
-    # FIRST pass: what a script that calls the identification functions once pays (examples/ur10/identification.py:71-83) --
-    # the pipeline forgets everything it has learnt from earlier passes (kept-column set, counts, per-block lists; the HBM
-    # buffers stay allocated) and runs one pass; median of five.  Collective-safe: every rank forgets and runs.
-    first_times = []
-    fused_before = pipe.fused_passes
-    for _ in range(5):
-        pipe.forget()
-        barrier()
-        ts = time.perf_counter()
-        pipe.run(wls=wls)
-        first_times.append(time.perf_counter() - ts)
-    first_fused = pipe.fused_passes - fused_before
-    # the small launches (merge levels, regrouped n x n factorisation, collectives) are timed in two extra,
-    # untimed passes so that their event records do not sit in the timed region
-    _lib.profile_enable(True, level=2)
-    _lib.profile_reset()
-    for _ in range(2):
-        pipe.run(wls=wls)
-    for name in ("triangle_residuals", "tsqr_tree", "tsqr_reduce", "select_columns", "rccl_allgather", "rccl_allreduce"):
-        cnt, ms = _lib.profile_get(name)
-        if cnt:
-            kern[name] = {"launches_per_step": cnt / 2.0, "avg_ms": ms / cnt, "timed_region": False}
-    _lib.profile_enable(False)
-    transfers = {"h2d_inputs_ms": 1e3 * t_h2d, "h2d_inputs_GBps": input_bytes / t_h2d / 1e9, "timed_region": False,
-                 # tree models: q, v, a re-laid per 64-sample tile once after the upload (figh_repack_samples), part of
-                 # "device-resident q, v, a -> result" but not of the repeated pass (the copies stay resident)
-                 "repack_inputs_ms": getattr(pipe, "repack_ms", 0.0)}
-    if rank == 0 and pipe.W is not None and getattr(pipe, "_compact", None) is None and pipe.W.buf.size * 8 <= 8e9:
-        # what the drop-in boundary pays when W itself is handed back to a NumPy caller (never part of `value`)
-        host_W = np.empty(pipe.W.buf.size)  # (the resident buffer: force-compact W is smaller than rows x ld)
+    def measure(args, steps, warmup, with_cpu):
+        """One BASELINE config measured on the ranks of this run: (line of rank 0 | None, structural result ok)."""
+        fixture, model_name, n_config, chunk = CONFIGS[args.config]
+        if args.chunk_samples and args.config == "cfg5":
+            chunk = args.chunk_samples
+        scaling = args.scaling or ("weak" if args.config == "cfg2" else "strong")
+        with open(os.path.join(ROOT, "tests", "golden", fixture + ".json")) as f:
+            meta = json.load(f)
+        robot = Robot.from_flat(model_name)
+        param = meta["param"]
+        params_std = dict(zip(meta["names_std"], meta["phi_ref_raw"]))
+        if scaling == "weak":
+            N = args.samples or n_config          # per GPU
+            n_total = N * world
+        else:
+            n_total = args.samples or n_config    # sharded: contiguous sample ranges (dist.shard_range)
+            lo, hi = shard_range(n_total, rank, world)
+            N = hi - lo
+        rng = np.random.default_rng(20250410 + int(args.config[3]) + 1000 * rank)
+        if args.config == "cfg2":  # examples/ur10/identification.py:71-81
+            q, v, a = (rng.uniform(-6, 6, (N, 6)) for _ in range(3))
+        else:
+            q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
+        row_blocks = None
+        if args.active_joints:
+            if args.config != "cfg3":
+                raise SystemExit("--active-joints is the TIAGo script's variant (cfg3)")
+            names = ["torso_lift_joint"] + ["arm_%d_joint" % k for k in range(1, 8)]
+            row_blocks = [robot.model.joints[robot.model.getJointId(n)].idx_v for n in names]
+        pipe = IdentificationPipeline(robot, param, params_std=params_std, coupling=meta["coupling"], exchange=exchange,
+                                      row_blocks=row_blocks,
+                                      chunk_samples=chunk, placement_trials=args.placement_trials,
+                                      structural_zeros=args.structural_zeros,
+                                      w_layout="dense" if args.w_layout == "dense" else "block-compact", fuse=not args.no_fuse,
+                                      null_pivots=not args.no_null_pivots)
         _lib.synchronize()
-        td = time.perf_counter()
-        _lib.check(lib.figh_memcpy_d2h(host_W.ctypes.data, pipe.W.buf.ptr, host_W.nbytes))
-        td = time.perf_counter() - td
-        transfers.update({"d2h_W_ms": 1e3 * td, "d2h_W_GBps": host_W.nbytes / td / 1e9, "W_bytes": host_W.nbytes})
-        del host_W
-    m = robot.model
-    rows_per_sample = m.nv if param["is_joint_torques"] else 6
-    ncols = len(meta["names_std"])
-    bytes_per_sample = 8 * (m.nq + 2 * m.nv) + 8 * rows_per_sample * ncols        # SURVEY 8(d), stage A
-    flops_per_sample = 2 * rows_per_sample * (n_kept + 1) ** 2                    # SURVEY 8(d), stage B: 2 m n^2
-    launches_per_step = {k: v["launches"] / float(args.steps) for k, v in kern.items() if "launches" in v}
-    roof = {}
-    if k1_name in kern:
-        sec = kern[k1_name]["avg_ms"] * 1e-3 * launches_per_step[k1_name]  # (the streamed pass runs K1' twice per chunk)
-        roof[k1_name] = {"bound": "hbm", "achieved": bytes_per_sample * N / sec / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_sample": bytes_per_sample}
-        if getattr(pipe, "_compact", None) is not None:
-            # block-compact W: the kernel is asked to write the N x 16 |subtree_j| window of every row block, not the
-            # reference's dense rows -- `achieved` / `frac` count the bytes this layout stores (every one of them is written
-            # in every pass); the rate on the reference's dense bytes is kept beside them and is not a fraction of anything
-            stored = 8 * (m.nq + 2 * m.nv) + 8 * float(pipe._compact[1].sum())
-            roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
-                                  "dense_bytes_per_sample": bytes_per_sample,
-                                  "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
-        if getattr(pipe, "_link_pos", None) is not None or getattr(pipe, "_force_ld", 0):
-            # link-compact / force-compact W: links without entries (massless bodies) have no columns, the force rows one
-            # line per four links; same accounting as above
-            stored = 8 * (m.nq + 2 * m.nv) + 8.0 * pipe.W.buf.size / pipe.N
-            roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
-                                  "dense_bytes_per_sample": bytes_per_sample,
-                                  "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
-    if "fused_chain_tsqr" in kern:
-        # one launch does stage A (the regressor, written to HBM) and stage B level 0 (the TSQR of the kept columns, out of
-        # LDS): its time is bounded from below by max(algorithmic bytes / HBM peak, algorithmic flops / fp64 peak); the
-        # larger of the two bounds is the roof it is measured against, the other one is reported beside it
-        sec = kern["fused_chain_tsqr"]["avg_ms"] * 1e-3 * launches_per_step["fused_chain_tsqr"]
-        gbs = bytes_per_sample * N / sec / 1e9
-        tfs = flops_per_sample * N / sec / 1e12
-        kept = np.array([meta["names_std"].index(p) for p in out["params_r"]])
-        first = np.searchsorted(kept, 14 * np.arange(rows_per_sample))
-        ex_flops = int(sum(2 * (n_kept + 1 - f) ** 2 for f in first))
-        hbm_bound = gbs / HBM_PEAK_GBS >= tfs / FP64_PEAK_TFLOPS
-        roof["fused_chain_tsqr"] = {
-            "bound": "hbm" if hbm_bound else "fp64",
-            "achieved": gbs if hbm_bound else tfs, "peak": HBM_PEAK_GBS if hbm_bound else FP64_PEAK_TFLOPS,
-            "unit": "GB/s" if hbm_bound else "TFLOP/s", "traffic": None,
-            "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_flops_per_sample": flops_per_sample,
-            "executed_flops_per_sample": ex_flops,
-            "hbm": {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS},
-            "fp64": {"achieved_TFLOPs": tfs, "frac": tfs / FP64_PEAK_TFLOPS, "executed_TFLOPs": ex_flops * N / sec / 1e12,
-                     "pipe": "fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand; no MFMA instruction is issued -- "
-                             "v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak and shares the FP64 datapath)"},
-            "what": "regressor rows produced by two waves per CU into LDS tiles, streamed to W (every byte of the 6N x 84 "
-                    "matrix written in every pass), each tile factored out of LDS by one of six consumer waves: W is not "
-                    "read back"}
-    if "tsqr" in kern:
-        sec = kern["tsqr"]["avg_ms"] * 1e-3 * launches_per_step["tsqr"]
-        roof["tsqr"] = {"bound": "fp64", "achieved": flops_per_sample * N / sec / 1e12, "peak": FP64_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "traffic": None, "algorithmic_flops_per_sample": flops_per_sample}
-        if n_kept + 1 <= 80:
-            roof["tsqr"]["pipe"] = ("fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand, no MFMA instruction is issued): "
-                                    "v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak and shares the FP64 datapath "
-                                    "(tools/microbench/latency.hip), so that peak is the roof of this kernel")
-            # the kernel skips the structurally zero leading columns of each joint's row block (structure hint): the
-            # flops it executes are 2 (nc - first_j)^2 per row of block j, not the dense 2 nc^2
+        t_h2d = time.perf_counter()
+        pipe.set_samples(q, v, a)
+        _lib.synchronize()
+        t_h2d = time.perf_counter() - t_h2d - 1e-3 * getattr(pipe, "repack_ms", 0.0)
+        input_bytes = q.nbytes + v.nbytes + a.nbytes
+        phi_ref = np.array([float(x) for x in meta["phi_ref_raw"]])
+        # cfg3 is quoted with a WLS solve (BASELINE configs[2]): measurement noise, or the per-joint variances are round-off
+        pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config in ("cfg2", "cfg3") else 0.0, seed=rank)
+        wls = args.config == "cfg3" and not args.no_wls
+        del q, v, a
+
+        out = None
+        # live HIP-event timing of the dominant kernels on the library stream (level 1: the event pair of K1 and of the TSQR
+        # level 0 is stamped by their own dispatch packets, hipExtLaunchKernelGGL -- no extra packets in the queue), switched
+        # on during warm-up already so that the event pool exists before the timed region
+        _lib.profile_enable(True, level=1)
+        for _ in range(warmup):
+            out = pipe.run(wls=wls)
+        _lib.profile_reset()
+        barrier()
+        step_times = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts = time.perf_counter()
+            out = pipe.run(wls=wls)  # returns when its results are on the host: the per-step clock needs no extra synchronisation
+            step_times.append(time.perf_counter() - ts)
+        barrier()
+        dt = time.perf_counter() - t0
+        _lib.profile_enable(False)
+        dt_rank = dt
+        if world > 1:
+            dt = max(group.all_gather_object(dt))
+
+        # sanity: the step produced the reference's structural result (cfg3 at 1e6 samples: four dependent pivots grow past
+        # TOL_QR like sqrt(N), LAPACK agrees -- DESIGN.md section 4 -- so only the eliminated columns are compared there)
+        ok = out["idx_e"] == [int(x) for x in np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))["idx_e"]]
+        if args.config != "cfg3":
+            ok = ok and out["idx_base"] == meta_idx(meta) and out["params_base"] == meta["params_base"]
+        elif world == 1 and N == 1_000_000 and not args.active_joints:
+            # cfg3 at the BASELINE size: the index set a LAPACK Householder TSQR of the oracle's W keeps for THESE samples
+            # (tests/golden/cfg3_tiago_large.json, oracle/pin_cfg3_large.py: 185 base parameters -- six pivots of the golden's
+            # dependent columns have grown past TOL_QR like sqrt(N))
+            with open(os.path.join(ROOT, "tests", "golden", "cfg3_tiago_large.json")) as f:
+                pin = next(c for c in json.load(f)["cases"] if c["N"] == N and c["seed"] == 20250410 + 3)
+            ok = ok and out["idx_base"] == pin["idx_base"]
+        n_kept = len(out["params_r"])
+        kern = {}
+        k1_name = "regressor_chain" if args.config == "cfg2" else "regressor_tree"
+        for name in (k1_name, "tsqr", "fused_chain_tsqr"):
+            cnt, ms = _lib.profile_get(name)
+            if cnt:
+                kern[name] = {"launches": cnt, "avg_ms": ms / cnt}
+        # FIRST pass: what a script that calls the identification functions once pays (examples/ur10/identification.py:71-83) --
+        # the pipeline forgets everything it has learnt from earlier passes (kept-column set, counts, per-block lists; the HBM
+        # buffers stay allocated) and runs one pass; median of five.  Collective-safe: every rank forgets and runs.
+        first_times = []
+        fused_before = pipe.fused_passes
+        for _ in range(5):
+            pipe.forget()
+            barrier()
+            ts = time.perf_counter()
+            pipe.run(wls=wls)
+            first_times.append(time.perf_counter() - ts)
+        first_fused = pipe.fused_passes - fused_before
+        # the small launches (merge levels, regrouped n x n factorisation, collectives) are timed in two extra,
+        # untimed passes so that their event records do not sit in the timed region
+        _lib.profile_enable(True, level=2)
+        _lib.profile_reset()
+        for _ in range(2):
+            pipe.run(wls=wls)
+        for name in ("triangle_residuals", "tsqr_tree", "tsqr_reduce", "select_columns", "rccl_allgather", "rccl_allreduce"):
+            cnt, ms = _lib.profile_get(name)
+            if cnt:
+                kern[name] = {"launches_per_step": cnt / 2.0, "avg_ms": ms / cnt, "timed_region": False}
+        _lib.profile_enable(False)
+        transfers = {"h2d_inputs_ms": 1e3 * t_h2d, "h2d_inputs_GBps": input_bytes / t_h2d / 1e9, "timed_region": False,
+                     # tree models: q, v, a re-laid per 64-sample tile once after the upload (figh_repack_samples), part of
+                     # "device-resident q, v, a -> result" but not of the repeated pass (the copies stay resident)
+                     "repack_inputs_ms": getattr(pipe, "repack_ms", 0.0)}
+        if rank == 0 and pipe.W is not None and getattr(pipe, "_compact", None) is None and pipe.W.buf.size * 8 <= 8e9:
+            # what the drop-in boundary pays when W itself is handed back to a NumPy caller (never part of `value`)
+            host_W = np.empty(pipe.W.buf.size)  # (the resident buffer: force-compact W is smaller than rows x ld)
+            _lib.synchronize()
+            td = time.perf_counter()
+            _lib.check(lib.figh_memcpy_d2h(host_W.ctypes.data, pipe.W.buf.ptr, host_W.nbytes))
+            td = time.perf_counter() - td
+            transfers.update({"d2h_W_ms": 1e3 * td, "d2h_W_GBps": host_W.nbytes / td / 1e9, "W_bytes": host_W.nbytes})
+            del host_W
+        m = robot.model
+        rows_per_sample = m.nv if param["is_joint_torques"] else 6
+        ncols = len(meta["names_std"])
+        bytes_per_sample = 8 * (m.nq + 2 * m.nv) + 8 * rows_per_sample * ncols        # SURVEY 8(d), stage A
+        flops_per_sample = 2 * rows_per_sample * (n_kept + 1) ** 2                    # SURVEY 8(d), stage B: 2 m n^2
+        launches_per_step = {k: v["launches"] / float(steps) for k, v in kern.items() if "launches" in v}
+        roof = {}
+        if k1_name in kern:
+            sec = kern[k1_name]["avg_ms"] * 1e-3 * launches_per_step[k1_name]  # (the streamed pass runs K1' twice per chunk)
+            roof[k1_name] = {"bound": "hbm", "achieved": bytes_per_sample * N / sec / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_sample": bytes_per_sample}
+            if getattr(pipe, "_compact", None) is not None:
+                # block-compact W: the kernel is asked to write the N x 16 |subtree_j| window of every row block, not the
+                # reference's dense rows -- `achieved` / `frac` count the bytes this layout stores (every one of them is written
+                # in every pass); the rate on the reference's dense bytes is kept beside them and is not a fraction of anything
+                stored = 8 * (m.nq + 2 * m.nv) + 8 * float(pipe._compact[1].sum())
+                roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
+                                      "dense_bytes_per_sample": bytes_per_sample,
+                                      "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
+            if getattr(pipe, "_link_pos", None) is not None or getattr(pipe, "_force_ld", 0):
+                # link-compact / force-compact W: links without entries (massless bodies) have no columns, the force rows one
+                # line per four links; same accounting as above
+                stored = 8 * (m.nq + 2 * m.nv) + 8.0 * pipe.W.buf.size / pipe.N
+                roof[k1_name].update({"achieved": stored * N / sec / 1e9, "algorithmic_bytes_per_sample": stored,
+                                      "dense_bytes_per_sample": bytes_per_sample,
+                                      "dense_equivalent_GBps": bytes_per_sample * N / sec / 1e9})
+        if "fused_chain_tsqr" in kern:
+            # one launch does stage A (the regressor, written to HBM) and stage B level 0 (the TSQR of the kept columns, out of
+            # LDS): its time is bounded from below by max(algorithmic bytes / HBM peak, algorithmic flops / fp64 peak); the
+            # larger of the two bounds is the roof it is measured against, the other one is reported beside it
+            sec = kern["fused_chain_tsqr"]["avg_ms"] * 1e-3 * launches_per_step["fused_chain_tsqr"]
+            gbs = bytes_per_sample * N / sec / 1e9
+            tfs = flops_per_sample * N / sec / 1e12
             kept = np.array([meta["names_std"].index(p) for p in out["params_r"]])
             first = np.searchsorted(kept, 14 * np.arange(rows_per_sample))
-            roof["tsqr"]["executed_flops_per_sample"] = int(sum(2 * (n_kept + 1 - f) ** 2 for f in first))
-        else:
-            roof["tsqr"]["pipe"] = ("fp64 matrix pipe: 16-column panels on the VALU, compact-WY trailing updates as "
-                                    "v_mfma_f64_16x16x4 (figh_tsqr_wide.hip); rows whose leading columns are zero start "
-                                    "at their first non-zero column, so the executed flops are below the dense 2 m n^2")
-            blocks = getattr(pipe, "_block_cache", None) if getattr(pipe, "_tree_blocks", False) else None
-            if blocks is not None:
-                # joint-torque regressor of a tree: every row block is factored over the columns of its joint's subtree only
-                # (figh_tsqr_selected_blocks).  The reference's dense count 2 m n^2 is then 40 x the flops this path is
-                # asked to execute, so `achieved` / `frac` are restated on the EXECUTED flops (they would exceed the peak
-                # otherwise) and the dense-equivalent rate is kept beside them.
-                ex = int(sum(2 * (int(c) + 1) ** 2 for c in blocks[1]))
-                roof["tsqr"]["algorithmic_equivalent_TFLOPs"] = roof["tsqr"]["achieved"]
-                roof["tsqr"]["executed_flops_per_sample"] = ex
-                roof["tsqr"]["achieved"] = ex * N / sec / 1e12
-                roof["tsqr"]["launches_per_step"] = launches_per_step["tsqr"]
-                roof["tsqr"]["pipe"] += ("; per-row-block column lists: `achieved` counts the executed flops "
-                                         "sum_j 2 (n_j + 1)^2 per sample, the launches are 24 small ones (7 .. 86 columns)")
-            if getattr(pipe, "_wrench_split", False) and getattr(pipe, "_nf_expected", 0) > 0:
-                # external wrench on a free-flyer root: the three force row blocks are factored over the nf columns that
-                # can be non-zero there (figh_tsqr_selected_wrench) -- `achieved` above counts the reference's dense
-                # 2 m n^2, the flops this path is asked to execute are fewer
-                nf = pipe._nf_expected
-                roof["tsqr"]["executed_flops_per_sample"] = int(3 * 2 * (nf + 1) ** 2 + 3 * 2 * (n_kept + 1) ** 2)
-                roof["tsqr"]["executed_TFLOPs"] = roof["tsqr"]["executed_flops_per_sample"] * N / sec / 1e12
-                roof["tsqr"]["frac_executed"] = roof["tsqr"]["executed_TFLOPs"] / FP64_PEAK_TFLOPS
-                roof["tsqr"]["launches_per_step"] = launches_per_step["tsqr"]
-    # HBM bytes per launch: PMC counters cannot be read from inside the process -- the number below comes from the
-    # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
-    # tools/pmc_summary.py), i.e. from the builder's run, not from this one
-    try:
-        pmc_file = next(n for n in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
-                        if os.path.exists(os.path.join(ROOT, "profiles", n)))
-        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-            pmc = json.load(f)
-        if args.config == "cfg2" and N == 1_000_000:
-            for key, kname in (("regressor_chain", "regressor_chain_kernel<6, false, true>"),
-                               ("tsqr", "tsqr2_kernel<4, 4, true>"), ("fused_chain_tsqr", "fused_chain_tsqr_kernel<6>")):
-                if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
-                    roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
-                    roof[key]["traffic_source"] = ("profiles/%s: a committed rocprofv3 --pmc run of this command, NOT "
-                                                   "measured in this run" % pmc_file)
-        if args.config == "cfg4" and N == 4_000_000:
-            pmc4 = next(n for n in ("r05_pmc_summary_cfg4.json", "r04_pmc_summary_cfg4.json", "r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
-                        if os.path.exists(os.path.join(ROOT, "profiles", n)))
-            with open(os.path.join(ROOT, "profiles", pmc4)) as f:
+            ex_flops = int(sum(2 * (n_kept + 1 - f) ** 2 for f in first))
+            hbm_bound = gbs / HBM_PEAK_GBS >= tfs / FP64_PEAK_TFLOPS
+            roof["fused_chain_tsqr"] = {
+                "bound": "hbm" if hbm_bound else "fp64",
+                "achieved": gbs if hbm_bound else tfs, "peak": HBM_PEAK_GBS if hbm_bound else FP64_PEAK_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s", "traffic": None,
+                "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_flops_per_sample": flops_per_sample,
+                "executed_flops_per_sample": ex_flops,
+                "hbm": {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS},
+                "fp64": {"achieved_TFLOPs": tfs, "frac": tfs / FP64_PEAK_TFLOPS, "executed_TFLOPs": ex_flops * N / sec / 1e12,
+                         "pipe": "fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand; no MFMA instruction is issued -- "
+                                 "v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak and shares the FP64 datapath)"},
+                "what": "regressor rows produced by two waves per CU into LDS tiles, streamed to W (every byte of the 6N x 84 "
+                        "matrix written in every pass), each tile factored out of LDS by one of six consumer waves: W is not "
+                        "read back"}
+        if "tsqr" in kern:
+            sec = kern["tsqr"]["avg_ms"] * 1e-3 * launches_per_step["tsqr"]
+            roof["tsqr"] = {"bound": "fp64", "achieved": flops_per_sample * N / sec / 1e12, "peak": FP64_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "traffic": None, "algorithmic_flops_per_sample": flops_per_sample}
+            if n_kept + 1 <= 80:
+                roof["tsqr"]["pipe"] = ("fp64 VALU (v_fmac_f64 with a DPP row_newbcast operand, no MFMA instruction is issued): "
+                                        "v_mfma_f64_16x16x4 has the same 78.6 TFLOP/s peak and shares the FP64 datapath "
+                                        "(tools/microbench/latency.hip), so that peak is the roof of this kernel")
+                # the kernel skips the structurally zero leading columns of each joint's row block (structure hint): the
+                # flops it executes are 2 (nc - first_j)^2 per row of block j, not the dense 2 nc^2
+                kept = np.array([meta["names_std"].index(p) for p in out["params_r"]])
+                first = np.searchsorted(kept, 14 * np.arange(rows_per_sample))
+                roof["tsqr"]["executed_flops_per_sample"] = int(sum(2 * (n_kept + 1 - f) ** 2 for f in first))
+            else:
+                roof["tsqr"]["pipe"] = ("fp64 matrix pipe: 16-column panels on the VALU, compact-WY trailing updates as "
+                                        "v_mfma_f64_16x16x4 (figh_tsqr_wide.hip); rows whose leading columns are zero start "
+                                        "at their first non-zero column, so the executed flops are below the dense 2 m n^2")
+                blocks = getattr(pipe, "_block_cache", None) if getattr(pipe, "_tree_blocks", False) else None
+                if blocks is not None:
+                    # joint-torque regressor of a tree: every row block is factored over the columns of its joint's subtree only
+                    # (figh_tsqr_selected_blocks).  The reference's dense count 2 m n^2 is then 40 x the flops this path is
+                    # asked to execute, so `achieved` / `frac` are restated on the EXECUTED flops (they would exceed the peak
+                    # otherwise) and the dense-equivalent rate is kept beside them.
+                    ex = int(sum(2 * (int(c) + 1) ** 2 for c in blocks[1]))
+                    roof["tsqr"]["algorithmic_equivalent_TFLOPs"] = roof["tsqr"]["achieved"]
+                    roof["tsqr"]["executed_flops_per_sample"] = ex
+                    roof["tsqr"]["achieved"] = ex * N / sec / 1e12
+                    roof["tsqr"]["launches_per_step"] = launches_per_step["tsqr"]
+                    roof["tsqr"]["pipe"] += ("; per-row-block column lists: `achieved` counts the executed flops "
+                                             "sum_j 2 (n_j + 1)^2 per sample, the launches are 24 small ones (7 .. 86 columns)")
+                if getattr(pipe, "_wrench_split", False) and getattr(pipe, "_nf_expected", 0) > 0:
+                    # external wrench on a free-flyer root: the three force row blocks are factored over the nf columns that
+                    # can be non-zero there (figh_tsqr_selected_wrench) -- `achieved` above counts the reference's dense
+                    # 2 m n^2, the flops this path is asked to execute are fewer
+                    nf = pipe._nf_expected
+                    roof["tsqr"]["executed_flops_per_sample"] = int(3 * 2 * (nf + 1) ** 2 + 3 * 2 * (n_kept + 1) ** 2)
+                    roof["tsqr"]["executed_TFLOPs"] = roof["tsqr"]["executed_flops_per_sample"] * N / sec / 1e12
+                    roof["tsqr"]["frac_executed"] = roof["tsqr"]["executed_TFLOPs"] / FP64_PEAK_TFLOPS
+                    roof["tsqr"]["launches_per_step"] = launches_per_step["tsqr"]
+        # HBM bytes per launch: PMC counters cannot be read from inside the process -- the number below comes from the
+        # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
+        # tools/pmc_summary.py), i.e. from the builder's run, not from this one
+        try:
+            pmc_file = next(n for n in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
-            src = "profiles/%s: a committed rocprofv3 --pmc run of this command, NOT measured in this run" % pmc4
-            wy = next((n for n in ("tsqr_wy_kernel<4, 5, 4, 2, true, 0>", "tsqr_wy_kernel<4, 5, 4, 2, true>") if n in pmc), "")
-            k1p = next((n for n in ("regressor_tape_kernel<16, true, true, true, true, true>",
-                                    "regressor_tape_kernel<16, true, true, true, true>") if n in pmc), "")
-            for key, kname in (("regressor_tree", k1p), ("tsqr", wy)):
-                if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
-                    roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
-                    roof[key]["traffic_source"] = src + (" (the torque-row launch of the two level-0 launches)" if key == "tsqr" else "")
-            k = pmc.get(wy, {})
-            if "tsqr" in roof and "SQ_INSTS_VALU_MFMA_MOPS_F64" in k:
-                # one MOPS unit = 512 flops (4 units per v_mfma_f64_16x16x4 = 2048 flops, checked against SQ_INSTS_MFMA)
-                roof["tsqr"]["executed_mfma_flops_per_launch"] = 512.0 * k["SQ_INSTS_VALU_MFMA_MOPS_F64"]
-                roof["tsqr"]["mfma_counters_source"] = src
-    except Exception:
-        pass
-    for r in roof.values():
-        r["frac"] = r["achieved"] / r["peak"]
-    main_k = {k: v for k, v in kern.items() if "launches" in v}
-    dominant = max(main_k, key=lambda k: main_k[k]["avg_ms"] * main_k[k]["launches"]) if main_k else None
+            if args.config == "cfg2" and N == 1_000_000:
+                for key, kname in (("regressor_chain", "regressor_chain_kernel<6, false, true>"),
+                                   ("tsqr", "tsqr2_kernel<4, 4, true>"), ("fused_chain_tsqr", "fused_chain_tsqr_kernel<6>")):
+                    if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
+                        roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
+                        roof[key]["traffic_source"] = ("profiles/%s: a committed rocprofv3 --pmc run of this command, NOT "
+                                                       "measured in this run" % pmc_file)
+            if args.config == "cfg4" and N == 4_000_000:
+                pmc4 = next(n for n in ("r05_pmc_summary_cfg4.json", "r04_pmc_summary_cfg4.json", "r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", n)))
+                with open(os.path.join(ROOT, "profiles", pmc4)) as f:
+                    pmc = json.load(f)
+                src = "profiles/%s: a committed rocprofv3 --pmc run of this command, NOT measured in this run" % pmc4
+                wy = next((n for n in ("tsqr_wy_kernel<4, 5, 4, 2, true, 0>", "tsqr_wy_kernel<4, 5, 4, 2, true>") if n in pmc), "")
+                k1p = next((n for n in ("regressor_tape_kernel<16, true, true, true, true, true>",
+                                        "regressor_tape_kernel<16, true, true, true, true>") if n in pmc), "")
+                for key, kname in (("regressor_tree", k1p), ("tsqr", wy)):
+                    if key in roof and kname in pmc and "hbm_bytes" in pmc[kname]:
+                        roof[key]["traffic"] = pmc[kname]["hbm_bytes"]
+                        roof[key]["traffic_source"] = src + (" (the torque-row launch of the two level-0 launches)" if key == "tsqr" else "")
+                k = pmc.get(wy, {})
+                if "tsqr" in roof and "SQ_INSTS_VALU_MFMA_MOPS_F64" in k:
+                    # one MOPS unit = 512 flops (4 units per v_mfma_f64_16x16x4 = 2048 flops, checked against SQ_INSTS_MFMA)
+                    roof["tsqr"]["executed_mfma_flops_per_launch"] = 512.0 * k["SQ_INSTS_VALU_MFMA_MOPS_F64"]
+                    roof["tsqr"]["mfma_counters_source"] = src
+        except Exception:
+            pass
+        for r in roof.values():
+            r["frac"] = r["achieved"] / r["peak"]
+        main_k = {k: v for k, v in kern.items() if "launches" in v}
+        dominant = max(main_k, key=lambda k: main_k[k]["avg_ms"] * main_k[k]["launches"]) if main_k else None
+        if rank == 0:
+            line = {
+                "metric": "samples/sec regressor build + TSQR solve, UR10 6-DoF" if args.config == "cfg2" else
+                          "samples/sec regressor build + TSQR solve, %s" % model_name,
+                "value": n_total * steps / dt,
+                "unit": "samples/s",
+                "n_gpus": world,
+                "steps": steps,
+                "warmup": warmup,
+                "ms_per_step": 1e3 * dt / steps,
+                "ms_per_step_median": 1e3 * float(np.median(step_times)),
+                "ms_per_step_min": 1e3 * float(np.min(step_times)),
+                "ms_first_pass": 1e3 * float(np.median(first_times)),
+                "higher_is_better": True,
+                "scaling": scaling,
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic",
+                "config": {
+                    "workload": {
+                        "cfg2": "BASELINE configs[1]: UR10 6-DoF, %d synthetic (q,qd,qdd) samples per GPU, full inertial "
+                                "regressor materialised (6N x 84) + elimination + Householder TSQR base params + LS" % N,
+                        "cfg3": "BASELINE configs[2]: TIAGo, fv/fs + actuator inertia + offset columns, %d samples in total, "
+                                "regressor (24N x 336, device-resident, link-padded) + elimination + blocked TSQR + LS%s" % (
+                                    n_total, " + WLS solve (per-joint variances from the OLS residuals, weighted factorisation "
+                                    "of the per-row-block triangles: %s)" % out.get("wls_source", "") if wls else
+                                    " (WLS left out: --no-wls)"),
+                        "cfg4": "BASELINE configs[3]: TALOS floating base, external-wrench regressor, %d samples in total "
+                                "sharded over the GPUs, regressor (6N x 462, device-resident, link-padded) + blocked TSQR" % n_total,
+                        "cfg5": "BASELINE configs[4]: human whole-body, %d samples in total sharded over the GPUs, %s" % (
+                            n_total, ("streamed in chunks of %s samples (W never exists in full)" % chunk) if chunk else
+                            "external-wrench regressor (6N x 560) device-resident in the link-compact layout (19 links with "
+                            "mass x 16 columns) + force / torque split TSQR"),
+                    }[args.config],
+                    "samples_this_rank": N, "samples_total": n_total, "columns": ncols, "kept_columns": n_kept,
+                    "base_parameters": len(out["idx_base"]), "collective": xinfo["collective"], "ranks": world,
+                    "rank0_seconds": dt_rank, "max_rank_seconds": dt,
+                    "device": _lib.device_info()["name"], "result_matches_reference": bool(ok),
+                    "figh_env": "none set (checked)", "host_wait": host_wait,
+                    "w_placement": pipe.placement_report or {"trials": 1},
+                    "w_layout": ("block-compact: row block j = N x 16 |subtree_j| (%.1f GB instead of %.1f GB)"
+                                 % (8e-9 * pipe.N * float(pipe._compact[1].sum()), 8e-9 * pipe.W.rows * pipe.W.ld))
+                    if getattr(pipe, "_compact", None) is not None else (
+                        ("force-compact: force rows %d columns (one line per four links) in front of the torque rows' %d%s; %.1f GB resident"
+                         % (pipe._force_ld, pipe.W.ld, (", link-compact: %d of %d links have columns" % (
+                             int((pipe._link_pos >= 0).sum()), len(pipe._link_pos))) if getattr(pipe, "_link_pos", None) is not None else "",
+                            8e-9 * pipe.W.buf.size))
+                        if getattr(pipe, "_force_ld", 0) else (
+                            "link-compact: %d of %d links have columns (%.1f GB resident)" % (
+                                int((pipe._link_pos >= 0).sum()), len(pipe._link_pos), 8e-9 * pipe.W.rows * pipe.W.ld)
+                            if getattr(pipe, "_link_pos", None) is not None else "dense")),
+                    "active_row_blocks": row_blocks,
+                    "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
+                    "null_pivots": ("on: columns null to tol_qr / 64 skip their column steps (figh_tsqr_null_pivot_tol)"
+                                    if pipe.null_pivots else "off"),
+                    "pivots": {"dependent_max": float(np.max(np.delete(out["absdiagR"], out["idx_base"]), initial=0.0)),
+                               "base_min": float(np.min(np.asarray(out["absdiagR"])[out["idx_base"]])), "tol_qr": pipe.tol_qr},
+                    "fused": ("K1 + level-0 TSQR in one launch (figh_regressor_tsqr_fused), %d of the %d timed and warm-up passes"
+                              % (pipe.fused_passes, steps + warmup + 7) +
+                              "; first passes (kept set from a 4096-sample prefix): %d of 5 fused" % first_fused) if pipe.fused_passes else
+                             "no (two launches: W written by K1, read back by the TSQR)",
+                },
+                "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
+                "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},
+                "transfers": transfers,
+            }
+            if with_cpu and world == 1 and args.config in ("cfg2", "cfg3"):
+                n_cpu = args.cpu_samples or (300000 if args.config == "cfg2" else 20000)
+                line["cpu_baseline"] = cpu_baseline(robot, args.config, param, 7, n_cpu, n_config)
+                line["cpu_baseline_fast"] = cpu_baseline_fast(robot, args.config, param, 7, n_cpu, n_config)
+                # BASELINE.md holds no published number for this metric; the ratio asked for is the one to the CPU path of
+                # the same pass measured in this run (fair-fast port; the faithful reference structure beside it)
+                # (`vs_baseline` stays null: the contract reserves it for a published number)
+                line["vs_cpu_baseline"] = {"fair_fast": line["value"] / line["cpu_baseline_fast"]["value"],
+                                           "faithful_reference_structure": line["value"] / line["cpu_baseline"]["value"],
+                                           "note": "ratios of `value` to the two CPU legs of THIS run; north_star's target is "
+                                                   ">= 50x over the faithful one"}
+        pipe = None  # (HBM back before the next config is set up)
+        return (line if rank == 0 else None), ok
+
+    line, ok = measure(args, args.steps, args.warmup, not args.no_cpu_baseline)
+    if args.strong_config and args.strong_config != args.config and ok:
+        # north_star words its scaling target as STRONG scaling ("\u2265 6x at 8 GPUs"); the headline workload above is quoted
+        # per GPU (weak).  So the same line carries a fixed-total-size measurement of a sharded BASELINE config (default
+        # cfg4: TALOS, 4e6 samples in total, contiguous shards) at every N, N = 1 included: value(N) / value(1) of THIS
+        # object is the strong-scaling curve
+        import argparse as _ap
+        sargs = _ap.Namespace(**dict(vars(args), config=args.strong_config, scaling="strong", samples=args.strong_samples,
+                                     chunk_samples=None, active_joints=False))
+        try:
+            sline, sok = measure(sargs, args.strong_steps, 2, False)
+            if rank == 0:
+                line["strong_scaling"] = {k: sline[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step",
+                                                                "ms_per_step_median", "scaling")}
+                line["strong_scaling"]["config"] = {k: sline["config"][k] for k in (
+                    "workload", "samples_this_rank", "samples_total", "collective", "ranks", "result_matches_reference",
+                    "max_rank_seconds", "w_layout")}
+                line["strong_scaling"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("launches", "launches_per_step", "avg_ms")}
+                                                     for k, v in sline["kernels"].items()}
+            ok = ok and sok
+        except Exception as e:  # noqa: BLE001  (the headline measurement stands on its own)
+            if world > 1:
+                raise  # a rank that leaves a collective pass alone would leave its peers waiting
+            line["strong_scaling"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
-        line = {
-            "metric": "samples/sec regressor build + TSQR solve, UR10 6-DoF" if args.config == "cfg2" else
-                      "samples/sec regressor build + TSQR solve, %s" % model_name,
-            "value": n_total * args.steps / dt,
-            "unit": "samples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "ms_per_step_median": 1e3 * float(np.median(step_times)),
-            "ms_per_step_min": 1e3 * float(np.min(step_times)),
-            "ms_first_pass": 1e3 * float(np.median(first_times)),
-            "higher_is_better": True,
-            "scaling": scaling,
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": {
-                    "cfg2": "BASELINE configs[1]: UR10 6-DoF, %d synthetic (q,qd,qdd) samples per GPU, full inertial "
-                            "regressor materialised (6N x 84) + elimination + Householder TSQR base params + LS" % N,
-                    "cfg3": "BASELINE configs[2]: TIAGo, fv/fs + actuator inertia + offset columns, %d samples in total, "
-                            "regressor (24N x 336, device-resident, link-padded) + elimination + blocked TSQR + LS%s" % (
-                                n_total, " + WLS solve (per-joint variances from the OLS residuals, weighted factorisation "
-                                "of the per-row-block triangles: %s)" % out.get("wls_source", "") if wls else
-                                " (WLS left out: --no-wls)"),
-                    "cfg4": "BASELINE configs[3]: TALOS floating base, external-wrench regressor, %d samples in total "
-                            "sharded over the GPUs, regressor (6N x 462, device-resident, link-padded) + blocked TSQR" % n_total,
-                    "cfg5": "BASELINE configs[4]: human whole-body, %d samples in total sharded over the GPUs, %s" % (
-                        n_total, ("streamed in chunks of %s samples (W never exists in full)" % chunk) if chunk else
-                        "external-wrench regressor (6N x 560) device-resident in the link-compact layout (19 links with "
-                        "mass x 16 columns) + force / torque split TSQR"),
-                }[args.config],
-                "samples_this_rank": N, "samples_total": n_total, "columns": ncols, "kept_columns": n_kept,
-                "base_parameters": len(out["idx_base"]), "collective": xinfo["collective"], "ranks": world,
-                "rank0_seconds": dt_rank, "max_rank_seconds": dt,
-                "device": _lib.device_info()["name"], "result_matches_reference": bool(ok),
-                "figh_env": "none set (checked)", "host_wait": host_wait,
-                "w_placement": pipe.placement_report or {"trials": 1},
-                "w_layout": ("block-compact: row block j = N x 16 |subtree_j| (%.1f GB instead of %.1f GB)"
-                             % (8e-9 * pipe.N * float(pipe._compact[1].sum()), 8e-9 * pipe.W.rows * pipe.W.ld))
-                if getattr(pipe, "_compact", None) is not None else (
-                    ("force-compact: force rows %d columns (one line per four links) in front of the torque rows' %d%s; %.1f GB resident"
-                     % (pipe._force_ld, pipe.W.ld, (", link-compact: %d of %d links have columns" % (
-                         int((pipe._link_pos >= 0).sum()), len(pipe._link_pos))) if getattr(pipe, "_link_pos", None) is not None else "",
-                        8e-9 * pipe.W.buf.size))
-                    if getattr(pipe, "_force_ld", 0) else (
-                        "link-compact: %d of %d links have columns (%.1f GB resident)" % (
-                            int((pipe._link_pos >= 0).sum()), len(pipe._link_pos), 8e-9 * pipe.W.rows * pipe.W.ld)
-                        if getattr(pipe, "_link_pos", None) is not None else "dense")),
-                "active_row_blocks": row_blocks,
-                "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
-                "null_pivots": ("on: columns null to tol_qr / 64 skip their column steps (figh_tsqr_null_pivot_tol)"
-                                if pipe.null_pivots else "off"),
-                "pivots": {"dependent_max": float(np.max(np.delete(out["absdiagR"], out["idx_base"]), initial=0.0)),
-                           "base_min": float(np.min(np.asarray(out["absdiagR"])[out["idx_base"]])), "tol_qr": pipe.tol_qr},
-                "fused": ("K1 + level-0 TSQR in one launch (figh_regressor_tsqr_fused), %d of the %d timed and warm-up passes"
-                          % (pipe.fused_passes, args.steps + args.warmup + 7) +
-                          "; first passes (kept set from a 4096-sample prefix): %d of 5 fused" % first_fused) if pipe.fused_passes else
-                         "no (two launches: W written by K1, read back by the TSQR)",
-            },
-            "roofline": dict(roof.get(dominant, {}), kernel=dominant) if dominant in roof else None,
-            "kernels": {k: dict(kern[k], **roof.get(k, {})) for k in kern},
-            "transfers": transfers,
-        }
-        if not args.no_cpu_baseline and world == 1 and args.config in ("cfg2", "cfg3"):
-            n_cpu = args.cpu_samples or (300000 if args.config == "cfg2" else 20000)
-            line["cpu_baseline"] = cpu_baseline(robot, args.config, param, 7, n_cpu, n_config)
-            line["cpu_baseline_fast"] = cpu_baseline_fast(robot, args.config, param, 7, n_cpu, n_config)
-            # BASELINE.md holds no published number for this metric; the ratio asked for is the one to the CPU path of
-            # the same pass measured in this run (fair-fast port; the faithful reference structure beside it)
-            line["vs_baseline"] = line["value"] / line["cpu_baseline_fast"]["value"]
-            line["vs_baseline_source"] = ("no published number exists (BASELINE.json published: {}); ratio of `value` to "
-                                          "cpu_baseline_fast of this run; vs the faithful reference structure: %.0fx" % (
-                                              line["value"] / line["cpu_baseline"]["value"]))
         print(json.dumps(line))
     if world > 1:
         barrier()
@@ -577,6 +616,47 @@ def main():
     if not ok:
         raise SystemExit("bench.py: the step did not reproduce the reference's structural result (idx_e / idx_base / "
                          "expressions) -- the line above is not a valid measurement")
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher (WORLD_SIZE unset): start N FRESH child processes of this script, one
+    per rank, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment (what
+    torch.distributed.run would set; the ranks meet over figaroh_plus_amd.dist.SocketGroup, so no PyTorch is involved), relay
+    their output and return the worst exit code.  The parent never loads the library or touches the GPU: nothing that has
+    initialised HIP is ever re-executed.  LOCAL_RANK modulo the device count picks the device; on a box with fewer GPUs
+    than ranks the ranks share devices and the exchange negotiates itself down to the host-staged one
+    (dist.exchange_from_env), which the line reports in config.collective."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        # (the children write to this process's stdout / stderr themselves: rank 0 prints the line)
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if failed and not worst:
+                worst = failed[0]
+                time.sleep(2.0)  # peers that fail for the same reason get to say so themselves ...
+                for other in procs:  # ... the rest would wait for the dead rank at the next exchange for ever
+                    if other.poll() is None:
+                        other.terminate()
+        worst = worst or next((p.returncode for p in procs if p.returncode != 0), 0)
+    except BaseException:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+    return worst if worst >= 0 else 1
 
 
 def meta_idx(meta):

@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIGH_LIB_PATH: another build of the same ABI (same-box A/B of kernel variants); default is the in-tree library
 LIB_PATH = os.environ.get("FIGH_LIB_PATH") or os.path.join(_HERE, "libfigh.so")
 
+ABI_VERSION = 106  # include/figh.h FIGH_ABI_VERSION: load() refuses a library of another ABI
+
 FIGH_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5
 
@@ -137,6 +139,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        have = lib.figh_version()
+        if have != ABI_VERSION:
+            raise ImportError("%s implements ABI %d, this package is written against %d (include/figh.h FIGH_ABI_VERSION): "
+                              "rebuild it (make -C figaroh_plus_amd/csrc)" % (LIB_PATH, have, ABI_VERSION))
         _lib = lib
     return _lib
 

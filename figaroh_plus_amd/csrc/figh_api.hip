@@ -202,7 +202,7 @@ using namespace figh;
 
 extern "C" {
 
-int figh_version(void) { return 100; }
+int figh_version(void) { return FIGH_ABI_VERSION; }
 
 const char *figh_last_error(void) { return g_error.c_str(); }
 
@@ -534,6 +534,9 @@ int figh_model_set_active_rows(figh_model_t model, const int32_t *h_rows, int n)
     FIGH_REQUIRE(model, "model is NULL");
     unsigned long long mask = ~0ull;
     if (h_rows && n > 0) {
+        // (the store decision is one bit per row block: a model with more than 64 dofs cannot restrict them -- rows >= 64
+        // would alias rows mod 64 in the tape builder)
+        FIGH_REQUIRE(model->host.nv <= 64, "active row blocks: at most 64 dofs");
         mask = 0ull;
         for (int k = 0; k < n; ++k) {
             FIGH_REQUIRE(h_rows[k] >= 0 && h_rows[k] < model->host.nv && h_rows[k] < 64, "active row block out of range");

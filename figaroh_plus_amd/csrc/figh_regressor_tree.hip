@@ -840,7 +840,7 @@ std::vector<TapeOp> build_tape_rows(const DevModel &h, int mode, int flags, int 
         int prev = -1, zero_from = -1;
         const bool compact = (flags & FIGH_FLAG_COMPACT_BLOCKS) != 0;
         // figh_model_set_active_rows: a row block that is not stored is still walked (its entries count in diag(W^T W))
-        const bool stored = ext || ((active_rows >> row) & 1ull);
+        const bool stored = ext || row >= 64 || ((active_rows >> row) & 1ull);  // (rows >= 64: always stored, see figh_model_set_active_rows)
         auto flush_zero = [&](int upto_link) {
             if (zero_from < 0) return;
             if (stored && !(flags & (FIGH_FLAG_ZEROS_PRESENT | FIGH_FLAG_COMPACT_BLOCKS)))
@@ -894,7 +894,7 @@ std::vector<TapeOp> build_tape_torque_rows(const DevModel &h, int flags, int ls,
         s1[j] = T.subtree_end(j);
         joint_of_row[h.idx_v[j]] = j;
     }
-    auto stored = [&](int row) { return ((active_rows >> row) & 1ull) != 0; };
+    auto stored = [&](int row) { return row >= 64 || ((active_rows >> row) & 1ull) != 0; };
     int compact_prefix = 0;
     for (int row = 0; row < h.nv; ++row) {  // block-compact: a row block's own leading dimension, 0 when it is not stored
         const int j = joint_of_row[row];

@@ -50,6 +50,11 @@ class GpuMatrix:
             # N sum_j ld_j doubles -- reading rows * ld doubles would run far past the allocation)
             raise ValueError("block-compact W is not a dense rows x ld matrix: read its row blocks through .compact "
                              "(element offsets, leading dimensions)")
+        if getattr(self, "force_ld", 0):
+            # (force-compact W of the external-wrench regressor: rows [0, rows / 2) live in a region of their own with
+            # leading dimension force_ld, the torque rows behind it -- the buffer is smaller than rows x ld)
+            raise ValueError("force-compact W is two matrices (force rows: .force_ld columns, torque rows behind them), not a "
+                             "dense rows x ld matrix; IdentificationPipeline(w_layout='link-compact') keeps one matrix")
         if self.ld == self.cols:
             out = np.empty((self.rows, self.cols))
             if out.size:

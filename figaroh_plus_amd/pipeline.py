@@ -202,11 +202,19 @@ class IdentificationPipeline:
         # about the next one), and under a collective exchange from a value all ranks agree on -- the fused launch needs at
         # least 4096 local samples, and ranks whose shards straddle that size must not take different paths through the
         # pass: one rank that cannot fuse keeps every rank on the two-launch path.
+        # The same holds for the force-compact layout of the external-wrench regressor: its consumer,
+        # figh_tsqr_selected_wrench, refuses a shard with fewer than 16 nc / 3 samples (three row blocks of N rows each must
+        # hold nc rows of 16-row tiles), and a rank-local fallback would re-run K1 and its collectives on that rank alone.
+        # Whether ANY rank's shard is too small for it is agreed here, once per sample set.
         self.fuse = self._fuse_requested
+        ncols_ref = self._handle().shape(mode, self._flags()[1])[1] if N > 0 else 0
+        self._force_compact_ok = N >= 64 and 3 * N >= 16 * (ncols_ref + 1)
         ex = self.exchange
-        if self.fuse and getattr(ex, "collective", False) and ex.world_size > 1:
-            flag = _lib.DeviceArray.from_host(np.array([0.0 if N >= 4096 else 1.0]))
-            self.fuse = float(np.asarray(ex.sum_columns(flag, 1)).reshape(-1)[0]) == 0.0
+        if getattr(ex, "collective", False) and ex.world_size > 1:
+            flag = _lib.DeviceArray.from_host(np.array([0.0 if N >= 4096 else 1.0, 0.0 if self._force_compact_ok else 1.0]))
+            agreed = np.asarray(ex.sum_columns(flag, 2)).reshape(-1)
+            self.fuse = self.fuse and float(agreed[0]) == 0.0
+            self._force_compact_ok = float(agreed[1]) == 0.0
             flag.free()
 
     def _flags(self):
@@ -383,7 +391,7 @@ class IdentificationPipeline:
             # pass reads W as one matrix (run(wls=True) re-creates W without it).
             self._force_ld = 0
             if (self._padded and self.w_layout in ("dense", "block-compact") and not getattr(self, "_no_force_compact", False)
-                    and self.N >= 64):
+                    and getattr(self, "_force_compact_ok", self.N >= 64)):
                 self._force_ld = _lib.regressor_force_layout(handle, mode, flags & 7, ft_mask)
             if (self.w_layout == "block-compact" and self._padded and mode == _lib.MODE_JOINT_TORQUE
                     and m.nv == m.njoints - 1 and self.N >= 64):
@@ -487,8 +495,9 @@ class IdentificationPipeline:
                 except _lib.FighError as e:
                     if not (self._force_ld and e.code == _lib.ERR_UNSUPPORTED):
                         raise
-                    # the kept columns turned out not to allow the force / torque split (at most 80 of them, or too few
-                    # rows): this regressor is kept as one matrix from now on
+                    # the kept columns turned out not to allow the force / torque split (at most 80 of them -- a property of
+                    # the all-reduced norms, the same on every rank; shards too short for it were ruled out for all ranks in
+                    # set_samples): this regressor is kept as one matrix from now on
                     self._no_force_compact = True
                     self.W.buf.free()
                     self.W = None

@@ -87,6 +87,11 @@ enum { FIGH_FLAG_FRICTION = 1, FIGH_FLAG_ACT_INERTIA = 2, FIGH_FLAG_OFFSET = 4, 
 typedef struct figh_model_s *figh_model_t;
 
 /* ------------------------------------------------------------------ runtime plumbing (no reference equivalent) */
+/* The ABI this header declares.  Bumped whenever an entry point changes its argument list or the meaning of an argument
+ * (round 5 did so for figh_tsqr_selected_wrench / figh_regressor_build_padded without a bump: a library of the older ABI
+ * accepts the longer argument list under cdecl and silently ignores the new arguments).  figaroh_plus_amd/_lib.py refuses a
+ * library -- in-tree or FIGH_LIB_PATH -- whose figh_version() differs from the value it was written against. */
+#define FIGH_ABI_VERSION 106
 int figh_version(void);
 const char *figh_last_error(void);
 int figh_device_count(int *count);

@@ -1340,15 +1340,19 @@ def test_calculate_standard_parameters_matches_reference(lib, golden):
     g = golden
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sip_qp.npz"))
     if g.name + "/cols" not in z.files:
-        if g.name == "cfg2_ur10":
-            # the base link is welded to the universe, whose inertia then has mass: the reference looks up 'Ixx0',
-            # which get_standard_parameters never writes -- KeyError there and here
-            W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
-            with pytest.raises(KeyError):
-                idt.calculate_standard_parameters(g.robot().model, W[:, :60], g["tau"], np.ones(18), -np.ones(18),
-                                                  g.params_std(), 0.33)
-            return
-        pytest.skip("no SIP fixture for this config")
+        # fixed-base models (TX40, UR10, TIAGo): the base link is welded to the universe, whose inertia then has mass
+        # (4.2 / 204 / 42.85 kg), so id_inertias starts at joint 0 and the reference looks up 'Ixx0', which
+        # get_standard_parameters never writes (identification_tools.py:497-514, robot.py:102-119) -- KeyError there and here.
+        # (The reference's function only ever runs on the floating-base models: examples/human/identification.py.)
+        model = g.robot().model
+        assert model.inertias[0].mass != 0 and g.name in ("cfg1_tx40", "cfg2_ur10", "cfg3_tiago")
+        nreal = sum(1 for i in model.inertias.tolist() if i.mass != 0)
+        W = _gpu_W(g, g["q_big"][:64], g["v_big"][:64], g["a_big"][:64])
+        cols = [14 * k + s for k in range(model.njoints - 1) for s in range(10)]
+        with pytest.raises(KeyError, match="Ixx0"):
+            idt.calculate_standard_parameters(model, W[:, cols], np.ones(len(W)), np.ones(3 * nreal), -np.ones(3 * nreal),
+                                              g.params_std(), 0.33)
+        return
     f = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(g.name + "/")}
     W = _gpu_W(g, g["q_big"], g["v_big"], g["a_big"])
     Wc = np.ascontiguousarray(W[:, f["cols"]])
@@ -1528,6 +1532,78 @@ def test_two_process_pipeline_on_one_device(lib, golden_ur10, tmp_path):
     assert res[0]["phi_ls"] == res[1]["phi_ls"]  # every rank reduces the same stack: bit-identical results
 
 
+def _two_device_ranks(tmp_path, models, same_device=False):
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0" if same_device else str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_rccl_worker.py"),
+                                       str(tmp_path / ("rank%d.json" % rank))] + list(models), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=800)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+
+
+def _check_two_rank_results(res, want_rccl):
+    from conftest import Golden
+    n, nc = 84, 7
+    want_sum = sum(np.arange(n, dtype=np.float64) * (r + 1) + 0.25 * r for r in range(2))
+    want_stack = np.concatenate([np.triu(np.arange(nc * nc, dtype=np.float64).reshape(nc, nc) + 100.0 * r).reshape(-1)
+                                 for r in range(2)])
+    A = [np.random.default_rng(40 + r).standard_normal((30 + r, 5)) for r in range(2)]
+    for r in res:
+        if want_rccl:
+            assert r["collective"] == "rccl" and r["exchange_class"] == "RcclExchange", r["collective"]
+        else:
+            assert "host-staged" in r["collective"] and "share a device" in r["collective"], r["collective"]
+        assert np.array_equal(r["sum_columns_device"], want_sum) and np.array_equal(r["sum_columns"], want_sum)
+        assert r["stack_count"] == 2 and np.array_equal(r["stack"], want_stack)
+        G = sum(a.T @ a for a in A)
+        assert np.abs(np.array(r["normal_terms"]["G"]) - G).max() <= 1e-13 * np.abs(G).max()
+        assert r["normal_terms"]["rows"] == 61.0
+    for cfg in res[0]["models"]:
+        g = Golden(cfg)
+        a_, b_ = res[0]["models"][cfg], res[1]["models"][cfg]
+        assert a_["phi_ls"] == b_["phi_ls"] and a_["absdiagR"] == b_["absdiagR"]  # both ranks reduce the same stack
+        for r in (a_, b_):
+            assert r["idx_e"] == list(g["idx_e"]) and r["idx_base"] == list(g["idx_base"])
+            assert r["params_base"] == g.meta["params_base"]
+            ref = g["phi_from_std"]
+            assert np.abs(np.array(r["phi_ls"]) - ref).max() <= 1e-6 * np.abs(ref).max()
+        if cfg == "cfg2_ur10":
+            assert a_["rows"] == 6 * (20000 + 37) and a_["fused_passes"] >= 1
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_worker_host_staged_on_one_device(lib, tmp_path):
+    """The worker of the two-device RCCL test below with both ranks on device 0: the exchange negotiates itself down to the
+    host-staged one, everything else -- primitives, the sharded UR10 (fused) and TALOS (wrench split) passes against the
+    golden results -- is the same code, so the two-device test does not meet the worker for the first time on a multi-GPU box."""
+    _check_two_rank_results(_two_device_ranks(tmp_path, ["cfg2_ur10", "cfg4_talos"], same_device=True), want_rccl=False)
+
+
+@pytest.mark.timeout(900)
+def test_rccl_two_devices_primitives_and_pipeline(lib, tmp_path):
+    """RCCL with N > 1 on real hardware (skipped on a one-GPU box): two fresh processes, rank r on device
+    r, exchange negotiated by dist.exchange_from_env over the socket control plane -- it must be RcclExchange.  Primitives on
+    device buffers: all-reduce of column norms (in place and returned), all-gather of the per-rank triangles in rank order,
+    the packed normal-terms all-reduce with unequal shards.  Then one sharded IdentificationPipeline pass per model -- UR10
+    (fused launch, narrow merge tree) and TALOS (wrench split, wide pair merges) -- against the golden idx_e / idx_base /
+    expressions / phi; both ranks reduce the same stack and must agree bit for bit."""
+    if lib.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's GPU test box has one); the same path is covered host-staged by "
+                    "test_two_process_pipeline_on_one_device and on CPU by tests/test_dist_cpu.py")
+    _check_two_rank_results(_two_device_ranks(tmp_path, ["cfg2_ur10", "cfg4_talos"]), want_rccl=True)
+
+
 def test_bench_two_ranks_share_the_device(lib):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU a test
     box has: both ranks drive device 0, so the exchange must be negotiated down to the host-staged one on every rank
@@ -1548,7 +1624,7 @@ def test_bench_two_ranks_share_the_device(lib):
         for k in [k for k in env if k.startswith("FIGH_")]:
             del env[k]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--strong-config", ""] + extra
         out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900).stdout.decode()
         lines = [l for l in out.splitlines() if l.startswith("{")]
         assert len(lines) == 1, out[-3000:]
@@ -1562,6 +1638,37 @@ def test_bench_two_ranks_share_the_device(lib):
     d = run(["--config", "cfg4", "--steps", "1", "--warmup", "1", "--samples", "200000"])
     assert d["scaling"] == "strong" and d["config"]["samples_this_rank"] == 100000 and d["config"]["samples_total"] == 200000
     assert d["config"]["result_matches_reference"] is True
+
+
+def test_bench_spawns_its_own_ranks(lib):
+    """`python bench.py --gpus 2` with NO launcher (WORLD_SIZE unset): bench.py starts two fresh rank processes itself
+    (bench.spawn_ranks: the parent never touches the GPU), the ranks meet over the socket control plane, rank 0 prints ONE
+    line with ranks = 2; on the one-GPU box both ranks share the device (host-staged exchange).  The line carries the
+    strong-scaling measurement of TALOS beside the weak-scaling headline."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FIGH_") and k not in (
+        "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--samples", "200000",
+           "--strong-samples", "200000", "--strong-steps", "2"]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = proc.stdout.decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert proc.returncode == 0 and len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["samples_total"] == 400000 and d["config"]["result_matches_reference"] is True
+    if lib.device_count() < 2:
+        assert "share a device" in d["config"]["collective"]
+    else:
+        assert d["config"]["collective"] == "rccl"
+    ss = d["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["n_gpus"] == 2 and ss["config"]["samples_total"] == 200000
+    assert ss["config"]["samples_this_rank"] == 100000 and ss["config"]["result_matches_reference"] is True
+    # a rank that fails takes the run down with a non-zero exit code instead of leaving its peer at a barrier
+    bad = subprocess.run(cmd + ["--config", "cfg9"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert bad.returncode != 0
 
 
 def test_bench_two_ranks_socket_rendezvous(lib):
@@ -1582,7 +1689,7 @@ def test_bench_two_ranks_socket_rendezvous(lib):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         for k in [k for k in env if k.startswith("FIGH_")]:
             del env[k]
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--strong-config", "", "--steps", "3",
                                        "--warmup", "2", "--samples", "200000", "--rendezvous", "socket"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
