@@ -368,13 +368,31 @@ def main():
                      "repack_inputs_ms": getattr(pipe, "repack_ms", 0.0)}
         if rank == 0 and pipe.W is not None and getattr(pipe, "_compact", None) is None and pipe.W.buf.size * 8 <= 8e9:
             # what the drop-in boundary pays when W itself is handed back to a NumPy caller (never part of `value`)
-            host_W = np.empty(pipe.W.buf.size)  # (the resident buffer: force-compact W is smaller than rows x ld)
+            from figaroh_plus_amd.device import host_empty
             _lib.synchronize()
             td = time.perf_counter()
+            # (allocation included: a fresh huge-page-backed array per call, as GpuMatrix.numpy() / build_regressor_basic
+            # return it; the resident buffer -- force-compact W is smaller than rows x ld)
+            host_W = host_empty(pipe.W.buf.size)
             _lib.check(lib.figh_memcpy_d2h(host_W.ctypes.data, pipe.W.buf.ptr, host_W.nbytes))
             td = time.perf_counter() - td
-            transfers.update({"d2h_W_ms": 1e3 * td, "d2h_W_GBps": host_W.nbytes / td / 1e9, "W_bytes": host_W.nbytes})
+            transfers.update({"d2h_W_ms": 1e3 * td, "d2h_W_GBps": host_W.nbytes / td / 1e9, "W_bytes": host_W.nbytes,
+                              "d2h_path": "fresh huge-page-backed ndarray (device.host_empty) + staged 32 MB chunks, 8 copy "
+                                          "threads (figh_memcpy_d2h)"})
             del host_W
+            if args.config == "cfg2":
+                # the whole drop-in call a FIGAROH script makes (regressor.py:20-194): host q, v, a in, host W out
+                from figaroh_plus_amd.tools.regressor import build_regressor_basic
+                rng2 = np.random.default_rng(1)
+                q2, v2, a2 = (rng2.uniform(-6, 6, (N, 6)) for _ in range(3))
+                build_regressor_basic(robot, q2[:1000], v2[:1000], a2[:1000], param)
+                _lib.synchronize()
+                td = time.perf_counter()
+                W_host = build_regressor_basic(robot, q2, v2, a2, param)
+                td = time.perf_counter() - td
+                transfers.update({"drop_in_build_regressor_basic_ms": 1e3 * td,
+                                  "drop_in_samples_per_s": N / td, "drop_in_W_shape": list(W_host.shape)})
+                del W_host, q2, v2, a2
         m = robot.model
         rows_per_sample = m.nv if param["is_joint_torques"] else 6
         ncols = len(meta["names_std"])
@@ -468,7 +486,7 @@ def main():
         # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
         # tools/pmc_summary.py), i.e. from the builder's run, not from this one
         try:
-            pmc_file = next(n for n in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
+            pmc_file = next(n for n in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
@@ -480,7 +498,7 @@ def main():
                         roof[key]["traffic_source"] = ("profiles/%s: a committed rocprofv3 --pmc run of this command, NOT "
                                                        "measured in this run" % pmc_file)
             if args.config == "cfg4" and N == 4_000_000:
-                pmc4 = next(n for n in ("r05_pmc_summary_cfg4.json", "r04_pmc_summary_cfg4.json", "r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
+                pmc4 = next(n for n in ("r06_pmc_summary_cfg4.json", "r05_pmc_summary_cfg4.json", "r04_pmc_summary_cfg4.json", "r03_pmc_summary_cfg4.json", "r02_pmc_summary_cfg4.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", n)))
                 with open(os.path.join(ROOT, "profiles", pmc4)) as f:
                     pmc = json.load(f)

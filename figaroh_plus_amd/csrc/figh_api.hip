@@ -3,7 +3,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -350,8 +352,107 @@ static void *pinned_staging() {
     return g_pinned;
 }
 
+static bool is_pinned(const void *p, size_t bytes);
+
+// Bulk transfers between PAGEABLE host memory and HBM (the drop-in boundary: the reference's functions take and return NumPy
+// arrays, src/figaroh/tools/regressor.py:20-194 -- a 4 GB W for UR10 at 1e6 samples): chunks of 32 MB go through two page-locked
+// staging buffers, the DMA of chunk k + 1 overlapping the host-side copy of chunk k, which eight threads share -- they also
+// take the page faults of a freshly allocated destination in parallel.  Measured on the GPU box (tools/microbench/d2h_probe*.hip,
+// profiles/r06_d2h_probe.txt): one hipMemcpyAsync into fresh pageable memory 12 - 24 GB/s, this path into a fresh
+// huge-page-backed buffer 48 GB/s (device.py allocates such buffers), into a page-locked buffer (figh_host_alloc) the plain
+// DMA reaches 57 GB/s.
+namespace {
+constexpr size_t kBulkChunk = size_t(32) << 20;
+constexpr size_t kBulkMin = size_t(24) << 20;
+constexpr int kBulkThreads = 8;
+char *g_bulk_stage[2] = {nullptr, nullptr};
+hipEvent_t g_bulk_ev[2];
+
+bool bulk_ready() {
+    if (g_bulk_stage[0]) return true;
+    void *a = nullptr, *b = nullptr;
+    if (hipHostMalloc(&a, kBulkChunk, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipHostMalloc(&b, kBulkChunk, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(a); return false; }
+    if (hipEventCreateWithFlags(&g_bulk_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_bulk_ev[1], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipHostFree(a); (void)hipHostFree(b);
+        return false;
+    }
+    g_bulk_stage[0] = static_cast<char *>(a);
+    g_bulk_stage[1] = static_cast<char *>(b);
+    return true;
+}
+
+// host <-> device in staged chunks; to_host: d -> h, else h -> d.  Returns a hipError_t.
+hipError_t bulk_copy(char *h, char *d, const size_t bytes, const bool to_host) {
+    const long nch = (long)((bytes + kBulkChunk - 1) / kBulkChunk);
+    const int nt = (int)std::max(1u, std::min<unsigned>(kBulkThreads, std::thread::hardware_concurrency()));
+    std::atomic<long> go{to_host ? 0 : 2};  // to_host: chunks < go sit in staging; else: chunks < go may be filled
+    std::atomic<long> done{0};              // thread-chunks copied
+    std::atomic<bool> abort{false};
+    auto span = [&](long k, size_t &lo, size_t &n) { lo = (size_t)k * kBulkChunk; n = std::min(kBulkChunk, bytes - lo); };
+    auto worker = [&](int t) {
+        for (long k = 0; k < nch; ++k) {
+            while (go.load(std::memory_order_acquire) <= k) {
+                if (abort.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            size_t lo, n;
+            span(k, lo, n);
+            const size_t per = ((n / nt) + 4095) & ~size_t(4095);
+            const size_t a = std::min(n, per * (size_t)t), b = std::min(n, a + per);
+            if (b > a) {
+                if (to_host) std::memcpy(h + lo + a, g_bulk_stage[k & 1] + a, b - a);
+                else std::memcpy(g_bulk_stage[k & 1] + a, h + lo + a, b - a);
+            }
+            done.fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(worker, t);
+    auto wait_done = [&](long chunks) { while (done.load(std::memory_order_acquire) < (long)nt * chunks) std::this_thread::yield(); };
+    hipError_t err = hipSuccess;
+    auto fail = [&](hipError_t e) { if (e != hipSuccess && err == hipSuccess) { err = e; abort.store(true); } return e != hipSuccess; };
+    size_t lo, n;
+    if (to_host) {
+        span(0, lo, n);
+        if (!fail(hipMemcpyAsync(g_bulk_stage[0], d, n, hipMemcpyDeviceToHost, g_stream))) fail(hipEventRecord(g_bulk_ev[0], g_stream));
+        for (long k = 0; k < nch && err == hipSuccess; ++k) {
+            if (k + 1 < nch) {
+                wait_done(k);  // chunk k - 1 has left the buffer chunk k + 1 lands in
+                span(k + 1, lo, n);
+                if (fail(hipMemcpyAsync(g_bulk_stage[(k + 1) & 1], d + lo, n, hipMemcpyDeviceToHost, g_stream))) break;
+                if (fail(hipEventRecord(g_bulk_ev[(k + 1) & 1], g_stream))) break;
+            }
+            if (fail(hipEventSynchronize(g_bulk_ev[k & 1]))) break;
+            go.store(k + 1, std::memory_order_release);
+        }
+    } else {
+        for (long k = 0; k < nch && err == hipSuccess; ++k) {
+            wait_done(k + 1);  // chunk k is in its staging buffer
+            span(k, lo, n);
+            if (fail(hipMemcpyAsync(d + lo, g_bulk_stage[k & 1], n, hipMemcpyHostToDevice, g_stream))) break;
+            if (fail(hipEventRecord(g_bulk_ev[k & 1], g_stream))) break;
+            if (k >= 1) {
+                if (fail(hipEventSynchronize(g_bulk_ev[(k - 1) & 1]))) break;  // chunk k - 1 has left its buffer: chunk k + 1 may be filled
+                go.store(k + 2, std::memory_order_release);
+            }
+        }
+    }
+    if (err != hipSuccess) abort.store(true);
+    for (auto &t : pool) t.join();
+    const hipError_t e2 = hipStreamSynchronize(g_stream);
+    return err != hipSuccess ? err : e2;
+}
+}  // namespace
+
 int figh_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes) {
     if (int rc = ensure_device()) return rc;
+    if (bytes >= kBulkMin && !is_pinned(h_src, bytes) && bulk_ready()) {
+        FIGH_HIP(hipStreamSynchronize(g_stream));  // (the staging buffers may still feed an earlier copy)
+        FIGH_HIP(bulk_copy(const_cast<char *>(static_cast<const char *>(h_src)), static_cast<char *>(d_dst), bytes, false));
+        return FIGH_OK;
+    }
     void *stage = bytes <= kPinnedBytes ? pinned_staging() : nullptr;
     if (stage) {
         FIGH_HIP(hipStreamSynchronize(g_stream));  // the staging buffer may still feed an earlier copy
@@ -406,6 +507,10 @@ int figh_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes) {
         FIGH_HIP(hipMemcpyAsync(stage, d_src, bytes, hipMemcpyDeviceToHost, g_stream));
         FIGH_HIP(hipStreamSynchronize(g_stream));
         std::memcpy(h_dst, stage, bytes);
+        return FIGH_OK;
+    }
+    if (bytes >= kBulkMin && !is_pinned(h_dst, bytes) && bulk_ready()) {
+        FIGH_HIP(bulk_copy(static_cast<char *>(h_dst), const_cast<char *>(static_cast<const char *>(d_src)), bytes, true));
         return FIGH_OK;
     }
     FIGH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_stream));

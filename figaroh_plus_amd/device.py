@@ -13,6 +13,36 @@ import numpy as np
 from . import _lib
 
 
+_HUGE = 2 << 20
+
+
+def host_empty(shape):
+    """Uninitialised float64 host array for a result that comes back from HBM.  Large ones (>= 64 MB) are backed by an
+    anonymous mapping advised to transparent huge pages: the first touch of a fresh 4 GB ``np.empty`` costs a million page
+    faults (the D2H copy then runs at 12 - 24 GB/s), 2 MB pages make that two thousand (48 GB/s through the staged copy of
+    ``figh_memcpy_d2h``; tools/microbench/d2h_probe2.hip).  An ordinary writable ndarray as far as the caller can tell: it owns
+    the mapping, which goes away with it."""
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    count = int(np.prod(shape)) if shape else 1
+    nbytes = 8 * count
+    if nbytes < (64 << 20):
+        return np.empty(shape)
+    try:
+        import mmap
+
+        m = mmap.mmap(-1, nbytes + _HUGE)
+        if hasattr(m, "madvise") and hasattr(mmap, "MADV_HUGEPAGE"):
+            try:
+                m.madvise(mmap.MADV_HUGEPAGE)
+            except OSError:  # (no THP on this kernel: plain pages, still correct)
+                pass
+        base = np.frombuffer(m, dtype=np.uint8)
+        off = (-base.ctypes.data) % _HUGE  # start on a huge-page boundary
+        return base[off:off + nbytes].view(np.float64).reshape(shape)
+    except (ImportError, OSError, ValueError, BufferError):
+        return np.empty(shape)
+
+
 class GpuMatrix:
     """rows x cols float64, row-major with leading dimension ``ld``, in HBM."""
 
@@ -56,11 +86,11 @@ class GpuMatrix:
             raise ValueError("force-compact W is two matrices (force rows: .force_ld columns, torque rows behind them), not a "
                              "dense rows x ld matrix; IdentificationPipeline(w_layout='link-compact') keeps one matrix")
         if self.ld == self.cols:
-            out = np.empty((self.rows, self.cols))
+            out = host_empty((self.rows, self.cols))
             if out.size:
                 _lib.check(_lib.load().figh_memcpy_d2h(out.ctypes.data, self.buf.ptr, out.nbytes))
             return out
-        full = np.empty((self.rows, self.ld))
+        full = host_empty((self.rows, self.ld))
         if full.size:
             _lib.check(_lib.load().figh_memcpy_d2h(full.ctypes.data, self.buf.ptr, full.nbytes))
         return np.ascontiguousarray(full[:, :self.cols])

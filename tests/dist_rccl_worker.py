@@ -52,7 +52,7 @@ def main(out_path, models):
         gold = Golden(cfg)
         robot = gold.robot()
         if cfg == "cfg2_ur10":  # (enough samples per rank for the fused launch: 4096)
-            q, v, a = (np.random.default_rng(6).uniform(-6, 6, (3, 20000 + 37, 6)))
+            q, v, a = (np.random.default_rng(6).uniform(-6, 6, (3, 20000 + 36, 6)))
         else:
             q, v, a = sample_inputs(robot.model, 30000 + 11, np.random.default_rng(5), 1.5, 2, 5)  # same on every rank
         N = len(q)

@@ -412,8 +412,16 @@ def test_full_size_tiago_and_rank_crossing(lib, oracle_lib, layout):
     W_ref = _oracle_W(g, oracle_lib, *qva)
     keep = [i for i in range(W_ref.shape[1]) if i not in set(out1["idx_e"])]
     d_ref = np.abs(np.diag(np.linalg.qr(W_ref[:, keep], mode="r")))
-    del W_ref
     big = d_ref > 1e-8
+    # phi against LAPACK on the same rows (north_star: 1e-6 relative): least squares of the oracle's base columns, from the
+    # Householder triangle of [W_b tau] (np.linalg.qr) and one triangular solve
+    from scipy.linalg import solve_triangular
+    tau_host = pipe.d_tau.to_host()
+    nb = int(big.sum())
+    Rb = np.linalg.qr(np.c_[W_ref[:, np.asarray(keep)[big]], tau_host], mode="r")
+    phi_lapack = solve_triangular(Rb[:nb, :nb], Rb[:nb, nb])
+    assert np.abs(out1["phi_ls"] - phi_lapack).max() <= 1e-6 * np.abs(phi_lapack).max()
+    del W_ref, Rb
     # (raw pivots of an UNPIVOTED QR are only comparable up to the direction of the noise reflectors of the dependent
     # columns in front of them -- SURVEY.md section 7 -- so: the decision exactly, the magnitudes loosely, and the four
     # borderline pivots, which carry the finding, tightly)
@@ -1492,6 +1500,37 @@ def test_regressor_all_flag_combinations(lib, golden, oracle_lib, flags):
         assert np.array_equal(W[:, ext], ref[:, ext])  # copies of v, a, sign(v), 1 and zeros: exact
 
 
+def test_bulk_host_device_copies_roundtrip(lib):
+    """figh_memcpy_h2d / figh_memcpy_d2h above 24 MB go through the staged path (32 MB page-locked chunks, eight copy threads):
+    ragged sizes around the chunk and page boundaries come back bit-identical, into plain, huge-page-backed (device.host_empty)
+    and page-locked destinations; GpuMatrix.numpy() of a padded matrix returns the reference's dense array."""
+    from figaroh_plus_amd.device import GpuMatrix, host_empty
+    rng = np.random.default_rng(0)
+    for n in (3 * (1 << 20) + 5, 4 * (1 << 20), 8 * (1 << 20) + 1, 12345679):  # doubles: 24 MB + 40 B ... 98.8 MB
+        src = rng.standard_normal(n)
+        d = lib.DeviceArray.from_host(src)
+        assert np.array_equal(d.to_host(), src)
+        out = host_empty(n)
+        lib.check(lib.load().figh_memcpy_d2h(out.ctypes.data, d.ptr, out.nbytes))
+        assert np.array_equal(out, src)
+        pin = lib.PinnedArray(n)
+        lib.check(lib.load().figh_memcpy_d2h(pin.array.ctypes.data, d.ptr, 8 * n))
+        assert np.array_equal(pin.array[:n], src)
+        d2 = lib.DeviceArray((n,), np.float64)
+        lib.check(lib.load().figh_memcpy_h2d(d2.ptr, pin.array.ctypes.data, 8 * n))  # page-locked source: plain DMA
+        assert np.array_equal(d2.to_host(), src)
+        pin.free()
+    big = host_empty((9_000_000, 1))
+    assert big.flags.writeable and big.flags.c_contiguous and big.ctypes.data % (2 << 20) == 0 and big.base is not None
+    A = rng.standard_normal((600_011, 14))
+    G = GpuMatrix.from_host(A)
+    assert np.array_equal(G.numpy(), A)
+    Gp = GpuMatrix.empty(600_011, 14, ld=16)
+    lib.check(lib.load().figh_memset(Gp.buf.ptr, 0, Gp.buf.nbytes))
+    lib.gather_cols(G.buf, G.rows, G.ld, lib.DeviceArray.from_host(np.arange(14, dtype=np.int32)), 14, Gp.buf, 16)
+    assert np.array_equal(Gp.numpy(), A)
+
+
 # ------------------------------------------------------------------------------------------------ two ranks, one GPU
 @pytest.mark.timeout(600)
 def test_two_process_pipeline_on_one_device(lib, golden_ur10, tmp_path):
@@ -1579,7 +1618,7 @@ def _check_two_rank_results(res, want_rccl):
             ref = g["phi_from_std"]
             assert np.abs(np.array(r["phi_ls"]) - ref).max() <= 1e-6 * np.abs(ref).max()
         if cfg == "cfg2_ur10":
-            assert a_["rows"] == 6 * (20000 + 37) and a_["fused_passes"] >= 1
+            assert a_["rows"] == 6 * (20000 + 36) and a_["fused_passes"] >= 1  # (equal shards: rows = this rank's x ranks)
 
 
 @pytest.mark.timeout(900)
