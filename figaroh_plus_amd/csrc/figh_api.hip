@@ -5,6 +5,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -388,7 +389,8 @@ hipError_t bulk_copy(char *h, char *d, const size_t bytes, const bool to_host) {
     const long nch = (long)((bytes + kBulkChunk - 1) / kBulkChunk);
     const int nt = (int)std::max(1u, std::min<unsigned>(kBulkThreads, std::thread::hardware_concurrency()));
     std::atomic<long> go{to_host ? 0 : 2};  // to_host: chunks < go sit in staging; else: chunks < go may be filled
-    std::atomic<long> done{0};              // thread-chunks copied
+    std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[nch]);  // per chunk: threads that have copied their slice
+    for (long k = 0; k < nch; ++k) done[k].store(0, std::memory_order_relaxed);
     std::atomic<bool> abort{false};
     auto span = [&](long k, size_t &lo, size_t &n) { lo = (size_t)k * kBulkChunk; n = std::min(kBulkChunk, bytes - lo); };
     auto worker = [&](int t) {
@@ -405,12 +407,13 @@ hipError_t bulk_copy(char *h, char *d, const size_t bytes, const bool to_host) {
                 if (to_host) std::memcpy(h + lo + a, g_bulk_stage[k & 1] + a, b - a);
                 else std::memcpy(g_bulk_stage[k & 1] + a, h + lo + a, b - a);
             }
-            done.fetch_add(1, std::memory_order_release);
+            done[k].fetch_add(1, std::memory_order_release);
         }
     };
     std::vector<std::thread> pool;
     for (int t = 0; t < nt; ++t) pool.emplace_back(worker, t);
-    auto wait_done = [&](long chunks) { while (done.load(std::memory_order_acquire) < (long)nt * chunks) std::this_thread::yield(); };
+    // (per CHUNK: a global count of thread-chunks would let a fast thread's next chunk stand in for a slow thread's current one)
+    auto wait_chunk = [&](long k) { while (done[k].load(std::memory_order_acquire) < nt) std::this_thread::yield(); };
     hipError_t err = hipSuccess;
     auto fail = [&](hipError_t e) { if (e != hipSuccess && err == hipSuccess) { err = e; abort.store(true); } return e != hipSuccess; };
     size_t lo, n;
@@ -419,7 +422,7 @@ hipError_t bulk_copy(char *h, char *d, const size_t bytes, const bool to_host) {
         if (!fail(hipMemcpyAsync(g_bulk_stage[0], d, n, hipMemcpyDeviceToHost, g_stream))) fail(hipEventRecord(g_bulk_ev[0], g_stream));
         for (long k = 0; k < nch && err == hipSuccess; ++k) {
             if (k + 1 < nch) {
-                wait_done(k);  // chunk k - 1 has left the buffer chunk k + 1 lands in
+                if (k >= 1) wait_chunk(k - 1);  // chunk k - 1 has left the buffer chunk k + 1 lands in
                 span(k + 1, lo, n);
                 if (fail(hipMemcpyAsync(g_bulk_stage[(k + 1) & 1], d + lo, n, hipMemcpyDeviceToHost, g_stream))) break;
                 if (fail(hipEventRecord(g_bulk_ev[(k + 1) & 1], g_stream))) break;
@@ -429,7 +432,7 @@ hipError_t bulk_copy(char *h, char *d, const size_t bytes, const bool to_host) {
         }
     } else {
         for (long k = 0; k < nch && err == hipSuccess; ++k) {
-            wait_done(k + 1);  // chunk k is in its staging buffer
+            wait_chunk(k);  // chunk k is in its staging buffer
             span(k, lo, n);
             if (fail(hipMemcpyAsync(d + lo, g_bulk_stage[k & 1], n, hipMemcpyHostToDevice, g_stream))) break;
             if (fail(hipEventRecord(g_bulk_ev[k & 1], g_stream))) break;

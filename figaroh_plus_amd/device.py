@@ -30,7 +30,9 @@ def host_empty(shape):
     try:
         import mmap
 
-        m = mmap.mmap(-1, nbytes + _HUGE)
+        # (PRIVATE anonymous memory: Python's default for fileno -1 is a SHARED mapping -- shmem pages, no transparent huge pages
+        # and a microsecond per fault: 3.9 GB/s measured)
+        m = mmap.mmap(-1, nbytes + _HUGE, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
         if hasattr(m, "madvise") and hasattr(mmap, "MADV_HUGEPAGE"):
             try:
                 m.madvise(mmap.MADV_HUGEPAGE)

@@ -1520,6 +1520,16 @@ def test_bulk_host_device_copies_roundtrip(lib):
         lib.check(lib.load().figh_memcpy_h2d(d2.ptr, pin.array.ctypes.data, 8 * n))  # page-locked source: plain DMA
         assert np.array_equal(d2.to_host(), src)
         pin.free()
+    # many chunks, position-dependent content (a chunk that lands in the wrong place, or a slice copied from a staging buffer
+    # the next DMA has already overwritten, changes the sequence), several repetitions: the pipeline of DMA and copy threads
+    n = 50_000_001
+    for rep in range(3):
+        src = np.arange(n, dtype=np.float64) * (rep + 1.0)
+        d = lib.DeviceArray.from_host(src)
+        out = host_empty(n) if rep % 2 == 0 else np.empty(n)
+        lib.check(lib.load().figh_memcpy_d2h(out.ctypes.data, d.ptr, out.nbytes))
+        assert np.array_equal(out, src)
+        d.free()
     big = host_empty((9_000_000, 1))
     assert big.flags.writeable and big.flags.c_contiguous and big.ctypes.data % (2 << 20) == 0 and big.base is not None
     A = rng.standard_normal((600_011, 14))
