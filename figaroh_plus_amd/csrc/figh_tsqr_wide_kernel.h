@@ -67,6 +67,10 @@ __device__ int g_wy_off = 0;  // FIGH_WY_OFF: wave relabelling per workgroup (wh
 __device__ int g_wy_delay_mode = 0, g_wy_delay_ticks = 0;  // FIGH_WY_DELAY="mode,ticks": start-up delay of some workgroups
 #endif
 
+#ifndef FIGH_WY_TMODE
+#define FIGH_WY_TMODE 0  // where T is formed: see wy_panel_step (0: inside the column steps; 2: once per panel -- measured in round 6, not faster)
+#endif
+
 constexpr int kLdv = 17;  // LDS row stride of V (doubles): the transposed reads of B -= V Wm hit 16 different banks
 
 constexpr int kLdt = 17;  // LDS row stride of T (doubles): T[row][col] at row * kLdt + col
@@ -103,7 +107,11 @@ struct TColumn<M1, M1> {
 // Rl = the 16 x 16 diagonal block in wave-private LDS (row-major), Tl = the T factor being built (LDS, zero-filled),
 // myinv = 1 / (alpha - beta) of reflector c (0 until column c has been factored).  Columns c < KK are finished
 // reflectors and stay frozen (they are V, up to the scaling by myinv).
-template <int KK, int RPL>
+// TMODE (round 6): 0 = column KK of T is formed INSIDE the step (larft forward, as described above: 15 DPP FMAs + the LDS
+// reads of T's row per step -- 106 of a step's 753 ticks, tools/microbench/step_bench.hip); 2 = the step only leaves the Gram
+// entries v_m^T v_KK (m < KK) and tau_KK in column KK of the T buffer and wy_larft_rows turns the buffer into T once per panel;
+// 1 = Gram entries only, no T at all (microbenchmark: the bound on what 2 can gain).
+template <int KK, int RPL, int TMODE = 0>
 __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, double *__restrict__ Rl,
                                               double *__restrict__ Tl, double *__restrict__ red, const int lane,
                                               const int c_, const double null2) {
@@ -115,7 +123,7 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
     double rk = Rl[KK * 16 + c];  // row KK of the diagonal block: requested before the dot products
     constexpr int KH = KK < 8 ? KK : 8;
     double tr[8];
-    TColumn<0, KH>::load(tr, Tl + c * kLdt);
+    if constexpr (TMODE == 0) TColumn<0, KH>::load(tr, Tl + c * kLdt);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
     for (int i = 0; i < RPL; i += 4) {
@@ -138,10 +146,12 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
     double vg = d * myinv;
     asm volatile("s_nop 1" : "+v"(vg));  // VALU write -> DPP read of vg below: 2 wait states
     double acc0 = 0.0, acc1 = 0.0;
-    TColumn<0, KH>::dot(acc0, acc1, tr, vg);
-    if constexpr (KK > 8) {
-        TColumn<8, KK>::load(tr, Tl + c * kLdt);
-        TColumn<8, KK>::dot(acc0, acc1, tr, vg);
+    if constexpr (TMODE == 0) {
+        TColumn<0, KH>::dot(acc0, acc1, tr, vg);
+        if constexpr (KK > 8) {
+            TColumn<8, KK>::load(tr, Tl + c * kLdt);
+            TColumn<8, KK>::dot(acc0, acc1, tr, vg);
+        }
     }
     // (round 5: the reciprocal of the scalars runs beside the rsq correction, householder_scalars4; starting the whole chain
     // in front of the test -- as the register-tile step now does -- costs this kernel 12 .. 16 more bytes of scratch in the
@@ -158,7 +168,8 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
     // sum of T's row entries is zero by itself for c >= KK (T is upper triangular, vg is zero there)
     if (lane < 16) {
         Rl[KK * 16 + c] = rk - wj;
-        Tl[c * kLdt + KK] = fma(-tfac * inv, acc0 + acc1, (c == KK) ? tfac : 0.0);
+        if constexpr (TMODE == 0) Tl[c * kLdt + KK] = fma(-tfac * inv, acc0 + acc1, (c == KK) ? tfac : 0.0);
+        else Tl[c * kLdt + KK] = (c == KK) ? tfac : vg * inv;  // v_c^T v_KK for c < KK (vg is zero from the diagonal on), tau_KK
     }
     myinv = (c == KK) ? inv : myinv;
     // the next step reads X through DPP operands of inline asm, which the hazard recognizer cannot see: nothing of it
@@ -166,9 +177,56 @@ __device__ __forceinline__ void wy_panel_step(double (&X)[RPL], double &myinv, d
     __builtin_amdgcn_sched_barrier(0);
 }
 
+template <int M, int K>
+struct LarftAxpy {  // Tr[k] += S[M][k] Tr[M] for k = K .. 15: independent FMAs, S[M][k] = lane-column M of the loaded column k
+    static __device__ __forceinline__ void run(const double (&col)[16], double (&Tr)[16]) {
+        if constexpr (K < 16) {
+            fmac_bcast<M>(Tr[K], col[K], Tr[M]);
+            LarftAxpy<M, K + 1>::run(col, Tr);
+        }
+    }
+};
+// right-looking: once T[r][M] is final it is added into every later column's sum at once -- the dependent chain is sixteen
+// short links (finalise, one FMA), not the 120 FMAs of the row-by-row dot products (measured: 2000 against 1900 ticks saved)
+template <int M>
+__device__ __forceinline__ void larft_row(const double (&col)[16], double (&Tr)[16], const int c) {
+    const double tau = row_bcast<M>(col[M]);
+    Tr[M] = (c == M) ? tau : -tau * Tr[M];
+    if constexpr (M < 15) {
+        LarftAxpy<M, M + 1>::run(col, Tr);
+        larft_row<M + 1>(col, Tr, c);
+    }
+}
+
+// TMODE 2: the T buffer holds S = strict upper part of V^T V with tau on the diagonal (a null pivot left its column zero);
+// larft forward, T[r][k] = -tau_k sum_{m = r .. k-1} T[r][m] S[m][k], T[k][k] = tau_k, is a recurrence along each ROW: lane r keeps
+// its row of T in registers and takes S[m][k] from lane-column m of the loaded column k through the DPP operand of the FMA -- 120
+// FMAs per lane, once per panel, in place of 120 + the row reloads spread over the sixteen column steps.  Every row group
+// computes the same rows; the first one writes T back over S.
+__device__ __forceinline__ void wy_larft_rows(double *__restrict__ Tl, const int lane, const int c) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double col[16], Tr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) col[k] = Tl[c * kLdt + k];  // lane c: S[c][k] (c < k), tau_k (c == k), 0 (c > k)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(col[k]));
+    asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Tr[k] = 0.0;
+    larft_row<0>(col, Tr, c);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (every lane has its column entries before the first one is overwritten)
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Tl[c * kLdt + k] = Tr[k];
+    }
+}
+
 // Factor one panel: on return Rl holds the new diagonal block, Vl (M x kLdv) the reflectors V = X diag(inv), Tl (16 x
 // kLdt, row-major) the T factor.
-template <int RPL>
+template <int RPL, int TMODE = FIGH_WY_TMODE>
 __device__ __forceinline__ void wy_factor_panel(double (&X)[RPL], double *__restrict__ Rl, double *__restrict__ red,
                                                 double *__restrict__ Vl, double *__restrict__ Tl, const int lane,
                                                 const int c, const int g, const double null2) {
@@ -190,22 +248,22 @@ __device__ __forceinline__ void wy_factor_panel(double (&X)[RPL], double *__rest
     for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(X[i]));
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    wy_panel_step<0, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<1, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<2, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<3, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<4, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<5, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<6, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<7, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<8, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<9, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<10, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<11, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<12, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<13, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<14, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
-    wy_panel_step<15, RPL>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<0, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<1, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<2, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<3, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<4, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<5, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<6, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<7, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<8, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<9, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<10, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<11, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<12, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<13, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<14, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
+    wy_panel_step<15, RPL, TMODE>(X, myinv, Rl, Tl, red, lane, c, null2);
     // null pivots: the norm of what the column still holds below the triangle moves into R_kk (all sixteen lane-columns at
     // once; nothing to do for columns that formed a reflector or are exactly zero)
     if (null2 > 0.0) {
@@ -227,6 +285,7 @@ __device__ __forceinline__ void wy_factor_panel(double (&X)[RPL], double *__rest
     }
 #pragma unroll
     for (int i = 0; i < RPL; ++i) Vl[(16 * (i >> 2) + 4 * (i & 3) + g) * kLdv + c] = X[i] * myinv;
+    if constexpr (TMODE == 2) wy_larft_rows(Tl, lane, c);
 }
 
 // Apply the panel's block reflector to one trailing chunk B (NRC row chunks of 16 x 16, C/D layout) and to its block of

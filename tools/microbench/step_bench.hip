@@ -92,6 +92,7 @@ int run(const char *label, double *out, long long *cyc) {
 // (a trailing sweep).  partner: 0 = chain waves only (1 per SIMD), 1 = every chain wave shares its SIMD with a second chain
 // wave, 2 = ... with an MFMA wave.
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
+template <int TMODE>
 __global__ __launch_bounds__(512) void k_panel(double *out, long long *cyc, const int passes, const int partner, const double seed) {
     __shared__ double rl[8][256], red[8][64], vl[8][64 * 17 + 16 * 17];
     __shared__ int stop;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(512) void k_panel(double *out, long long *cyc, cons
                 X[i] = keep[i];
                 asm volatile("" : "+v"(X[i]));
             }
-            wy_factor_panel<16>(X, rl[wave], red[wave], vl[wave], vl[wave] + 64 * 17, lane, c, g, 0.0);
+            wy_factor_panel<16, TMODE>(X, rl[wave], red[wave], vl[wave], vl[wave] + 64 * 17, lane, c, g, 0.0);
         }
         const long long t1 = __builtin_readcyclecounter();
         out[threadIdx.x] = X[0] + rl[wave][lane];
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(512) void k_panel(double *out, long long *cyc, cons
     }
 }
 
+template <int TMODE>
 int run_panel(double *out, long long *cyc) {
     const int passes = 300;
     const char *what[4] = {"alone on its SIMD", "next to a second panel chain", "next to a wave streaming v_mfma_f64_16x16x4",
@@ -143,14 +145,15 @@ int run_panel(double *out, long long *cyc) {
     for (int partner = 0; partner < 4; ++partner) {
         long long best = 1LL << 60;
         for (int r = 0; r < 3; ++r) {
-            hipLaunchKernelGGL(k_panel, dim3(1), dim3(partner == 0 ? 256 : 512), 0, 0, out, cyc, passes, partner, 1.0 + r);
+            hipLaunchKernelGGL(k_panel<TMODE>, dim3(1), dim3(partner == 0 ? 256 : 512), 0, 0, out, cyc, passes, partner, 1.0 + r);
             long long h[8];
             CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
             long long worst = 0;
             for (int w = 0; w < 4; ++w) worst = h[w] > worst ? h[w] : worst;
             best = worst < best ? worst : best;
         }
-        printf("panel chain of the blocked kernel (16 steps on 64 x 16) %-46s %7.1f ticks per column step\n", what[partner],
+        printf("panel chain of the blocked kernel (16 steps on 64 x 16; %s) %-46s %7.1f ticks per column step\n",
+               TMODE == 0 ? "T inside the steps" : TMODE == 1 ? "Gram entries only, NO T" : "Gram entries + one larft per panel", what[partner],
                (double)best / (passes * 16));
     }
     return 0;
@@ -161,7 +164,9 @@ int main() {
     long long *cyc;
     CHECK(hipMalloc(&out, sizeof(double) * 4096));
     CHECK(hipMalloc(&cyc, sizeof(long long) * 64));
-    if (run_panel(out, cyc)) return 1;
+    if (run_panel<0>(out, cyc)) return 1;
+    if (run_panel<1>(out, cyc)) return 1;
+    if (run_panel<2>(out, cyc)) return 1;
     if (run<4, 1>("one chunk, 64-row tile (last panel)", out, cyc)) return 1;
     if (run<8, 1>("one chunk, 128 rows (last panel of two tiles)", out, cyc)) return 1;
     if (run<4, 2>("two chunks, 64-row tile (panels 2, 3)", out, cyc)) return 1;
