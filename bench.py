@@ -286,6 +286,8 @@ def main():
                                       structural_zeros=args.structural_zeros,
                                       w_layout="dense" if args.w_layout == "dense" else "block-compact", fuse=not args.no_fuse,
                                       null_pivots=not args.no_null_pivots)
+        # (the page-locked staging buffers of the bulk copies are allocated by the first large transfer: not part of the rate)
+        _lib.DeviceArray.from_host(np.zeros(4 << 20)).free()
         _lib.synchronize()
         t_h2d = time.perf_counter()
         pipe.set_samples(q, v, a)
@@ -482,6 +484,10 @@ def main():
                     roof["tsqr"]["executed_TFLOPs"] = roof["tsqr"]["executed_flops_per_sample"] * N / sec / 1e12
                     roof["tsqr"]["frac_executed"] = roof["tsqr"]["executed_TFLOPs"] / FP64_PEAK_TFLOPS
                     roof["tsqr"]["launches_per_step"] = launches_per_step["tsqr"]
+                    # (the fraction of the roof is the one on the flops the kernels are asked to execute; the rate
+                    # on the reference's dense 2 m n^2 is kept beside it and is not a fraction of anything)
+                    roof["tsqr"]["dense_equivalent_TFLOPs"] = roof["tsqr"]["achieved"]
+                    roof["tsqr"]["achieved"] = roof["tsqr"]["executed_TFLOPs"]
         # HBM bytes per launch: PMC counters cannot be read from inside the process -- the number below comes from the
         # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 as the gfx950 correction + WRITE_SIZE,
         # tools/pmc_summary.py), i.e. from the builder's run, not from this one

@@ -2217,8 +2217,16 @@ def test_null_pivot_rule_never_changes_the_base_set(lib, cfg, sizes):
             # (with random samples both base regressors are ill-conditioned -- TIAGo: one base parameter comes out at 4e6 with
             # 0.05 of noise on tau, TX40 with its coupling columns at 1e5 -- and ANY two Householder orders differ by
             # cond(W_b) eps in phi: the fit itself, the residual, is what is compared to 1e-9)
-            phi_tol = 1e-2
-            assert np.abs(on_["phi_b"] - off["phi_b"]).max() <= phi_tol * max(1.0, np.abs(off["phi_b"]).max())
+            # (round 6: the bound is the conditioning the run itself reports, not a constant -- two backward-stable solves of the
+            # same least-squares problem differ by O(cond(R1) eps) relative to |phi|, and max |R_kk| / min |R_kk| over the base
+            # columns bounds cond(R1) from below; 1e-2 only where near-tolerance pivots (1e-8) sit in the base set.  The
+            # comparison with LAPACK on the same rows is in test_full_size_tiago_and_rank_crossing)
+            base_d = off["absdiagR"][np.asarray(off["idx_base"])]
+            cond_est = base_d.max() / base_d.min()
+            phi_tol = min(1e-2, max(1e-9, 4096 * np.finfo(float).eps * cond_est))
+            # (phi_b is rounded to 6 decimals, qrdecomposition.py:161: two units of that rounding are the floor)
+            assert np.abs(on_["phi_b"] - off["phi_b"]).max() <= max(2e-6, phi_tol * max(1.0, np.abs(off["phi_b"]).max())), (
+                cfg, N, seed, cond_est)
             assert abs(on_["residual_norm"] - off["residual_norm"]) <= 1e-9 * off["residual_norm"]
             dep = np.setdiff1d(np.arange(len(off["absdiagR"])), off["idx_base"])
             d_on, d_off = on_["absdiagR"][dep], off["absdiagR"][dep]
