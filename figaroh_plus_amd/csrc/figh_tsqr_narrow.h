@@ -80,8 +80,8 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
         double s0 = 0.0, s1 = 0.0;  // two chains (the second wave of the SIMD covers the FMA latency): 2 movs + 1 add
 #pragma unroll
         for (int i = 0; i < NR; i += 2) {
-            fmac_bcast<KK>(s0, S.T[P][i], S.T[P][i]);
-            fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P][i + 1]);
+            fmac_bcast_live<KK>(s0, S.T[P][i], S.T[P][i]);
+            fmac_bcast_live<KK>(s1, S.T[P][i + 1], S.T[P][i + 1]);
         }
         d[0] = tsqr2_reduce<LDSRED>(S, s0 + s1);
     }
@@ -163,7 +163,7 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
         const double nn = S.lane_c == KK ? -1.0 : 0.0;
         const double ncj = live ? -wl * inv : nn;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) fmac_bcast<KK>(S.T[P][i], S.T[P][i], ncj);
+        for (int i = 0; i < NR; ++i) fmac_bcast_live<KK>(S.T[P][i], S.T[P][i], ncj);
         if (RLAST && LIVE == 1) {
             if (S.lane_g == g0) S.Rq[slot] = Rk[0] - wj;
         } else {

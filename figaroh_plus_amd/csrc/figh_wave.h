@@ -9,6 +9,10 @@
 
 #include <hip/hip_runtime.h>
 
+#ifndef FIGH_NARROW_BANKMASK
+#define FIGH_NARROW_BANKMASK 1
+#endif
+
 namespace figh {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -60,6 +64,22 @@ __device__ __forceinline__ double allreduce_rowgroups_lds(double *red, const int
 template <int K>
 __device__ __forceinline__ void fmac_bcast(double &acc, const double pv, const double b) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pv), "v"(b), "n"(K));
+}
+
+// The same with the banks of four lane-columns that lie entirely LEFT of column K switched off (DPP bank_mask: a disabled bank
+// keeps its accumulator): in the pivot chunk of column step K the lane-columns c < K are finished -- their entries are zeros and
+// stay zeros either way -- so up to twelve of a row's sixteen lanes need not execute the FMA.  Round 6, on by default
+// (FIGH_NARROW_BANKMASK): the fused launch is clocked down by the power management (2.03 GHz, profiles/r06_pmc_clock.txt) and
+// the same instruction stream with fewer active lanes runs 1 - 3 % faster (same-box A/B, four alternating pairs: fused kernel
+// 1.344 - 1.369 ms against 1.361 - 1.411, profiles/r06_bankmask_ab.txt); results are bit-identical where they are read.
+template <int K>
+__device__ __forceinline__ void fmac_bcast_live(double &acc, const double pv, const double b) {
+#if FIGH_NARROW_BANKMASK
+    constexpr int BM = 0xf & ~((1 << (K / 4)) - 1);
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4" : "+v"(acc) : "v"(pv), "v"(b), "n"(K), "n"(BM));
+#else
+    fmac_bcast<K>(acc, pv, b);
+#endif
 }
 
 // Householder scalars of the stacked column [alpha; x], sigma = x^T x != 0 (LAPACK dlarfg without the rescaling
