@@ -294,6 +294,15 @@ def main():
         _lib.synchronize()
         t_h2d = time.perf_counter() - t_h2d - 1e-3 * getattr(pipe, "repack_ms", 0.0)
         input_bytes = q.nbytes + v.nbytes + a.nbytes
+        # ... and the copies alone, into a buffer that exists (set_samples above also allocates three device arrays)
+        d_probe = _lib.DeviceArray((max(q.size, v.size),), np.float64)
+        _lib.synchronize()
+        t_copy = time.perf_counter()
+        for arr in (q, v, a):
+            _lib.check(lib.figh_memcpy_h2d(d_probe.ptr, arr.ctypes.data, arr.nbytes))
+        _lib.synchronize()
+        t_copy = time.perf_counter() - t_copy
+        d_probe.free()
         phi_ref = np.array([float(x) for x in meta["phi_ref_raw"]])
         # cfg3 is quoted with a WLS solve (BASELINE configs[2]): measurement noise, or the per-joint variances are round-off
         pipe.set_tau_from_parameters(phi_ref, noise_std=0.05 if args.config in ("cfg2", "cfg3") else 0.0, seed=rank)
@@ -365,6 +374,8 @@ def main():
                 kern[name] = {"launches_per_step": cnt / 2.0, "avg_ms": ms / cnt, "timed_region": False}
         _lib.profile_enable(False)
         transfers = {"h2d_inputs_ms": 1e3 * t_h2d, "h2d_inputs_GBps": input_bytes / t_h2d / 1e9, "timed_region": False,
+                     "h2d_note": "set_samples: three device allocations + the copies; the copies alone: h2d_copy_*",
+                     "h2d_copy_ms": 1e3 * t_copy, "h2d_copy_GBps": input_bytes / t_copy / 1e9,
                      # tree models: q, v, a re-laid per 64-sample tile once after the upload (figh_repack_samples), part of
                      # "device-resident q, v, a -> result" but not of the repeated pass (the copies stay resident)
                      "repack_inputs_ms": getattr(pipe, "repack_ms", 0.0)}
