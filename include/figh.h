@@ -127,6 +127,13 @@ int figh_device_pci_bus_id(int device, char *out, int out_len);
 int figh_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
 int figh_malloc(void **d_ptr, size_t bytes);
 int figh_free(void *d_ptr);
+/* Host <-> HBM copies on the library stream; both return when the data has arrived (h2d below 1 MB: when it is queued in
+ * stream order).  This is where the reference's host-resident NumPy arrays cross the boundary: q, v, a in, and the stacked
+ * regressor out when a caller keeps W = build_regressor_basic(...) as an ndarray (regressor.py:20-194: 4.03 GB for UR10 at 1e6
+ * samples).  Transfers of 24 MB and more between PAGEABLE memory and HBM run in 32 MB chunks through two page-locked staging
+ * buffers -- the DMA of chunk k + 1 beside the host copy of chunk k, shared by eight threads (which also take a fresh
+ * destination's page faults in parallel): D2H 50 GB/s, H2D 27 - 55 GB/s on the GPU box (round 5, one hipMemcpyAsync per array:
+ * 24 and 7.5).  A figh_host_alloc buffer is copied by plain DMA (57 GB/s).  Smaller transfers stage through one 1 MB buffer. */
 int figh_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
 int figh_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
 /* Page-locked host memory for results that come back every pass (the (nc + 1) x nc rows of the rank step: 0.9 MB for
