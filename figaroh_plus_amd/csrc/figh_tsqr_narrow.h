@@ -6,6 +6,10 @@
 
 #include "figh_wave.h"
 
+#ifndef FIGH_NARROW_LDSTRAIL
+#define FIGH_NARROW_LDSTRAIL 0
+#endif
+
 namespace figh {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -133,7 +137,9 @@ __device__ __forceinline__ void tsqr2_step(Tsqr2State<NCC, NRC, RLAST> &S) {
             fmac_bcast<KK>(s0, S.T[P][i], S.T[P + cc][i]);
             fmac_bcast<KK>(s1, S.T[P][i + 1], S.T[P + cc][i + 1]);
         }
-        d[cc] = tsqr2_reduce<LDSRED>(S, s0 + s1);
+        // (FIGH_NARROW_LDSTRAIL, round-6 experiment on the fused launch: the sums of the TRAILING chunks -- off the step's dependent
+        // chain -- through the wave's 512 B of LDS instead of four lane swaps: 3 VALU instructions instead of 10)
+        d[cc] = tsqr2_reduce<LDSRED || (FIGH_NARROW_LDSTRAIL && RLAST)>(S, s0 + s1);
     }
     if (live) {
         // w_j = tau (R_kj + v^T B_j) for EVERY lane-column, no masks:
