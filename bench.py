@@ -591,8 +591,12 @@ def main():
                             if getattr(pipe, "_link_pos", None) is not None else "dense")),
                     "active_row_blocks": row_blocks,
                     "structural_zeros": args.structural_zeros + (" (in effect)" if getattr(pipe, "_zeros_once", False) else ""),
-                    "null_pivots": ("on: columns null to tol_qr / 64 skip their column steps (figh_tsqr_null_pivot_tol)"
-                                    if pipe.null_pivots else "off"),
+                    "null_pivots": ("on: columns null to tol_qr / 64 skip their column steps (figh_tsqr_null_pivot_tol); every pass "
+                                    "certified against plain Householder afterwards (_host.null_rule_certified)"
+                                    if pipe.null_pivots else (
+                                        "off: a pass could not be certified (pivot close to tol_qr) and was repeated without the rule; "
+                                        "the rule stays off (fallbacks: %d)" % pipe.null_rule_fallbacks
+                                        if getattr(pipe, "null_rule_fallbacks", 0) else "off")),
                     "pivots": {"dependent_max": float(np.max(np.delete(out["absdiagR"], out["idx_base"]), initial=0.0)),
                                "base_min": float(np.min(np.asarray(out["absdiagR"])[out["idx_base"]])), "tol_qr": pipe.tol_qr},
                     "fused": ("K1 + level-0 TSQR in one launch (figh_regressor_tsqr_fused), %d of the %d timed and warm-up passes"

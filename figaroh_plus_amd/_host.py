@@ -99,3 +99,67 @@ def relative_percent(sigma, phi):
     np.divide(100.0 * sigma, phi, out=out, where=phi != 0.0)
     out[(phi == 0.0) & (sigma == 0.0)] = np.nan  # (0 / 0, as NumPy has it)
     return np.round(out, 2)
+
+
+NULL_RULE_FOLD = 64.0  # the null-pivot rule folds at most tol_qr / 64 of a column's norm (include/figh.h)
+
+
+def null_rule_bounds(R1, R2):
+    """(A_base, A_dep) for :func:`null_rule_certified` from the regrouped factorisation ``qr([W1 W2]) = [R1 R2; 0 ~0]``:
+    how much a perturbation of the earlier columns can move a column's pivot.  ``A_dep[c] = sum_i |beta_ic|`` (the dependent
+    column is ``sum_i beta_ic b_i``), ``A_base[k] = |R1_kk| sum_{i<k} |(R1^-1)_ik|`` (= ``sum |R1[:k,:k]^-1 R1[:k,k]|``: the
+    coefficients of base column k's projection on the base columns in front of it).  None when R1 is singular."""
+    import numpy as np
+    from scipy.linalg.lapack import dtrtri
+    r = R1.shape[0]
+    if r == 0:
+        return np.zeros(0), np.zeros(R2.shape[1] if R2.ndim == 2 else 0)
+    if not np.diag(R1).all():
+        return None
+    X, info = dtrtri(np.ascontiguousarray(R1), lower=0)
+    if info != 0 or not np.isfinite(X).all():
+        return None
+    X = np.triu(X)
+    A_base = np.abs(np.diag(R1)) * (np.abs(X).sum(axis=0) - np.abs(np.diag(X)))
+    A_dep = np.abs(X @ R2).sum(axis=0) if R2.size else np.zeros(0)
+    return A_base, A_dep
+
+
+def null_rule_certified(absdiag, idx_base, idx_regroup, bounds, tol_qr, safety=2.0):
+    """A-posteriori GUARD for a factorisation that ran WITH the null-pivot rule (``figh_tsqr_null_pivot_tol``): True when the
+    classification ``|R_kk| > tol_qr`` can be trusted to be the one plain Householder -- the reference's ``np.linalg.qr``,
+    qrdecomposition.py:205-221 -- gives on the same matrix; not certified = the caller repeats the factorisation WITHOUT the
+    rule, so that what it returns is the reference's classification in every case.
+
+    The rule makes R the exact factor of ``W + E``: in every level-0 triangle at most ``tol_qr / 64`` of a column's norm is
+    folded without a reflector, so the later columns keep their component along that direction.  A pivot is the distance of
+    its column from the span of the columns in front of it; to first order ``|R_kk|`` moves by at most ``(1 + A_k) |E|``, A_k =
+    the 1-norm of the coefficients that express the column (dependent) or its projection (base) through the base columns in
+    front of it (:func:`null_rule_bounds`).  Three conditions, all on the numbers of the pass itself:
+
+    * every base pivot lies further above ``tol_qr`` and every dependent pivot further below it than
+      ``safety (1 + A_k) tol_qr / 64``: no decision sits within reach of the perturbation, and LARGE REGROUPING COEFFICIENTS --
+      the failure tools/fuzz_trees.py found in round 6: random trees with cond(W_b) ~ 1e14, coefficients in the hundreds, a
+      spurious base pivot of 1.1e-7 -- fail it (a spurious base column shows as a tiny ``R1_kk`` with a huge ``A_k``);
+    * no dependent pivot above ``tol_qr / 8``: a column that is classified dependent but carries that much genuine content of
+      its own (TIAGo at 4e5 samples: 6.7e-9) may have had ALL of it folded -- over T level-0 triangles the folded parts add up
+      to ``sqrt(T) tol_qr / 64`` in the worst case, include/figh.h -- and its direction then leaks into the columns behind it;
+      the rounding residue of an exactly dependent column stays far below (1e-12 .. 1.5e-10 at 1e7 samples);
+    * finite numbers throughout.
+
+    For the five BASELINE robots A <= 9 and UR10, TALOS and the human model are certified at their full sizes; TIAGo, whose
+    regressor has genuine pivots within 6 % of ``tol_qr`` at 1e6 samples, is not and runs without the rule.  A guard, not a
+    proof: the bound uses the per-triangle folding limit for |E| (a column that folds its maximum in EVERY triangle has a
+    residual of its own near the tolerance scale and trips the second condition)."""
+    import numpy as np
+    if bounds is None:
+        return False
+    A_base, A_dep = bounds
+    fold = safety * tol_qr / NULL_RULE_FOLD
+    d = np.abs(np.asarray(absdiag, dtype=np.float64))
+    db, dd = d[np.asarray(idx_base, dtype=np.int64)], d[np.asarray(idx_regroup, dtype=np.int64)]
+    if not (np.isfinite(db).all() and np.isfinite(dd).all()):
+        return False
+    if dd.size and dd.max() > tol_qr / 8.0:
+        return False
+    return bool(np.all(db - tol_qr > (1.0 + A_base) * fold) and np.all(tol_qr - dd > (1.0 + A_dep) * fold))

@@ -101,7 +101,12 @@ class IdentificationPipeline:
         # while it is still in LDS, W is written but not read back.  The list is verified against the norms the pass produces;
         # a pass whose kept set changed falls back to the two launches below (and learns the new list).
         self.fuse = self._fuse_requested = bool(fuse)
-        self.null_pivots = bool(null_pivots)
+        # null_pivots: the TSQR launches of a pass run under the null-pivot rule (include/figh.h) and the pass is certified
+        # afterwards; a pass that cannot be certified is repeated without the rule, which then stays off until the next
+        # set_samples (null_rule_fallbacks counts those)
+        self.null_pivots = self._null_pivots_requested = bool(null_pivots)
+        self.null_rule_fallbacks = 0
+        self._cert_cache = None
         self._fused_kept = None
         self.fused_passes = 0
         # structural_zeros = "once" (opt-in, joint-torque regressor of a tree kept in HBM): W is zero-filled when it is
@@ -207,6 +212,8 @@ class IdentificationPipeline:
         # hold nc rows of 16-row tiles), and a rank-local fallback would re-run K1 and its collectives on that rank alone.
         # Whether ANY rank's shard is too small for it is agreed here, once per sample set.
         self.fuse = self._fuse_requested
+        self.null_pivots = self._null_pivots_requested  # (a new sample set gets the rule -- and its certificate -- again)
+        self._cert_cache = None
         ncols_ref = self._handle().shape(mode, self._flags()[1])[1] if N > 0 else 0
         self._force_compact_ok = N >= 64 and 3 * N >= 16 * (ncols_ref + 1)
         ex = self.exchange
@@ -338,24 +345,40 @@ class IdentificationPipeline:
         is verified against the device's own afterwards; the first pass (count unknown) and a pass whose count changed
         repeat the solve with the right one."""
         # (null_pivots: the dependent columns of the regressor -- |R_kk| <= tol_qr by a margin of 64 -- cost a norm per tile
-        # instead of a column step in every TSQR launch of the pass, include/figh.h: figh_tsqr_null_pivot_tol)
-        with _lib.null_pivots(self.tol_qr if self.null_pivots else None):
-            if self._chunked():
-                if wls:
-                    raise NotImplementedError("wls=True needs the regressor resident in HBM (no chunk_samples)")
-                return self._run_chunked(strings)
-            if wls and not getattr(self, "_no_force_compact", False):
-                # the weighted solve's second pass reads W as ONE matrix: from now on without the force-compact region
-                self._no_force_compact = True
-                if getattr(self, "_force_ld", 0) and self.W is not None:
-                    self.W.buf.free()
-                    self.W = None
-            # (with the WLS the expression strings of the base parameters -- host work, 0.2 - 0.4 ms for TIAGo -- are built while
-            # the weighted factorisation runs on the device)
-            out = self._run_resident(strings and not wls, wls)
-            if wls:
-                self._wls(out, strings)
+        # instead of a column step in every TSQR launch of the pass, include/figh.h: figh_tsqr_null_pivot_tol.  Round 6: a pass
+        # that ran under the rule is CERTIFIED afterwards (_finish, _host.null_rule_certified): when its classification is not
+        # provably plain Householder's -- a pivot close to tol_qr, or regrouping coefficients large enough for the folded
+        # tol_qr / 64 to matter -- the pass is repeated without the rule and the rule stays off for this pipeline.)
+        for _ in range(2):
+            with _lib.null_pivots(self.tol_qr if self.null_pivots else None):
+                out = self._run_once(strings, wls)
+            if self.null_pivots and not out.get("null_rule_certified", True):
+                self.null_pivots = False
+                self.null_rule_fallbacks = getattr(self, "null_rule_fallbacks", 0) + 1
+                # (kept for diagnostics, tools/cert_report.py: the bounds and the pivots of the pass that was not certified)
+                self._cert_failed = (self._cert_cache, out["absdiagR"].copy(), list(out["idx_base"]))
+                self._cert_cache = None
+                continue
             return out
+        return out
+
+    def _run_once(self, strings, wls):
+        if self._chunked():
+            if wls:
+                raise NotImplementedError("wls=True needs the regressor resident in HBM (no chunk_samples)")
+            return self._run_chunked(strings)
+        if wls and not getattr(self, "_no_force_compact", False):
+            # the weighted solve's second pass reads W as ONE matrix: from now on without the force-compact region
+            self._no_force_compact = True
+            if getattr(self, "_force_ld", 0) and self.W is not None:
+                self.W.buf.free()
+                self.W = None
+        # (with the WLS the expression strings of the base parameters -- host work, 0.2 - 0.4 ms for TIAGo -- are built while
+        # the weighted factorisation runs on the device)
+        out = self._run_resident(strings and not wls, wls)
+        if wls and out.get("null_rule_certified", True):
+            self._wls(out, strings)
+        return out
 
     def _run_resident(self, strings, wls):
         ex = self.exchange
@@ -572,6 +595,7 @@ class IdentificationPipeline:
         self._mask_expected = None
         self._block_cache = None
         self._chunk_kept = None
+        self._cert_cache = None
 
     PREFIX_SAMPLES = 4096
 
@@ -898,6 +922,18 @@ class IdentificationPipeline:
         assert len(params_r) == n, "params_r does not have same length with R"
         Rb = rows_k[base]
         R1, R2, z = Rb[:, base], Rb[:, rest], (Rb[:, n] if with_tau else None)
+        certified = True
+        if self.null_pivots:
+            # the certificate of the null-pivot rule (_host.null_rule_certified): the coefficient sums come from the regrouped
+            # triangle and are kept while the two index sets stay the same (they are properties of the model's geometry far more
+            # than of the samples); the margins are this pass's own pivots
+            from ._host import null_rule_bounds, null_rule_certified
+            key = (n, base.tobytes())
+            cache = getattr(self, "_cert_cache", None)
+            if cache is None or cache[0] != key:
+                with _single_threaded_blas(n):
+                    cache = self._cert_cache = (key, null_rule_bounds(np.triu(R1), R2))
+            certified = null_rule_certified(diag[:n], idx_base, idx_regroup, cache[1], self.tol_qr)
         # inv(R1) of qrdecomposition.py:244 by LAPACK's triangular inverse (dtrtri): R1 is upper triangular (the routine
         # reads the upper triangle only; below it the device leaves rounding residues), and np.linalg.inv's general LU
         # path pays ~30 us of BLAS thread start-up per call on a many-core host
@@ -925,6 +961,8 @@ class IdentificationPipeline:
             "idx_e": idx_e, "params_r": params_r, "idx_base": idx_base, "beta": beta,
             "col_norm": col_norm, "absdiagR": diag[:n].copy(), "rows": total_rows,
         }
+        if self.null_pivots:
+            out["null_rule_certified"] = certified
         if strings and beta is not None:
             out["params_base"] = qrd._expressions([params_r[i] for i in idx_base],
                                                   [params_r[i] for i in idx_regroup], beta)

@@ -13,6 +13,7 @@ import numpy as np
 
 from .. import _lib
 from .._host import host_tail
+from .._host import null_rule_bounds, null_rule_certified
 from .._host import single_threaded_blas
 from ..device import GpuMatrix, index_to_device, to_device, vector_to_device
 
@@ -87,13 +88,37 @@ def _base_columns(Wd, idx, keep_on_device=False):
     return out if keep_on_device else out.numpy()
 
 
+def _factor_and_select(Wd, params_r, tol_qr, null_pivots, tau=None):
+    """(R, idx_base, idx_regroup, R1, R2, Q1^T tau | None): the triangle of ``[W_e (tau)]``, the selection
+    (qrdecomposition.py:215-221) and the regrouped factorisation.  With ``null_pivots`` the factorisation runs under the
+    null-pivot rule and its classification is CERTIFIED against plain Householder afterwards (``_host.null_rule_certified``);
+    a matrix for which the certificate does not hold -- pivots close to ``tol_qr``, or regrouping coefficients so large that
+    the folded ``tol_qr / 64`` could matter -- is factored again without the rule: what comes back is always the
+    classification of the reference's arithmetic."""
+    n = len(params_r)
+    for rule in ((True, False) if null_pivots else (False,)):
+        R = rfactor(Wd, tau=tau, tol_qr=tol_qr if rule else None)
+        assert R.shape[0] == n + (1 if tau is not None else 0), "params_r does not have same length with R"
+        idx_base, idx_regroup = _select(np.diag(R)[:n], params_r, tol_qr)
+        R1, R2, q1t_tau = _regroup(R, idx_base, idx_regroup, tau is not None)
+        if not rule:
+            break
+        with single_threaded_blas():
+            bounds = null_rule_bounds(R1, R2)
+        if null_rule_certified(np.diag(R)[:n], idx_base, idx_regroup, bounds, tol_qr):
+            break
+    return R, idx_base, idx_regroup, R1, R2, q1t_tau
+
+
 @host_tail
 def get_baseIndex(W_e, params_r, tol_qr=TOL_QR, null_pivots=True):
     """Indices of the linearly independent columns (qrdecomposition.py:274-296).  ``null_pivots=False`` (not a reference
     argument): plain Householder steps on every column, the reference's LAPACK arithmetic step for step, instead of the
-    null-pivot rule of include/figh.h (columns that are zero to tol_qr / 64 below the triangle skip their reflector)."""
-    R = rfactor(W_e, tol_qr=tol_qr if null_pivots else None)
-    idx_base, _ = _select(np.diag(R), params_r, tol_qr)
+    null-pivot rule of include/figh.h (columns that are zero to tol_qr / 64 below the triangle skip their reflector).  With
+    the rule the classification is certified afterwards and the factorisation repeated without it when the certificate does
+    not hold (:func:`_factor_and_select`): the index set is the reference's either way."""
+    Wd, _ = to_device(W_e)
+    _, idx_base, _, _, _, _ = _factor_and_select(Wd, params_r, tol_qr, null_pivots)
     return tuple(idx_base)
 
 
@@ -107,9 +132,7 @@ def build_baseRegressor(W_e, idx_base):
 def get_baseParams(W_e, params_r, params_std=None, tol_qr=TOL_QR, null_pivots=True):
     """(W_b, params_base, idx_base) -- qrdecomposition.py:190-271.  ``null_pivots``: see :func:`get_baseIndex`."""
     Wd, on_dev = to_device(W_e)
-    R = rfactor(Wd, tol_qr=tol_qr if null_pivots else None)
-    idx_base, idx_regroup = _select(np.diag(R), params_r, tol_qr)
-    R1, R2, _ = _regroup(R, idx_base, idx_regroup, False)
+    _, idx_base, idx_regroup, R1, R2, _ = _factor_and_select(Wd, params_r, tol_qr, null_pivots)
     with single_threaded_blas():  # n x n host work: see _host.py
         beta = np.around(np.matmul(np.linalg.inv(R1), R2), 6)
     params_base = _expressions([params_r[i] for i in idx_base], [params_r[i] for i in idx_regroup], beta)
@@ -123,12 +146,8 @@ def double_QR(tau, W_e, params_r, params_std=None, tol_qr=TOL_QR, null_pivots=Tr
     """(W_b, base_parameters, params_base, phi_b[, phi_std]) -- qrdecomposition.py:89-187.  ``null_pivots``: see
     :func:`get_baseIndex`."""
     Wd, on_dev = to_device(W_e)
-    R = rfactor(Wd, tau=tau, tol_qr=tol_qr if null_pivots else None)
-    n = len(params_r)
-    assert R.shape[0] == n + 1, "params_r does not have same length with R"
-    idx_base, idx_regroup = _select(np.diag(R)[:n], params_r, tol_qr)
+    _, idx_base, idx_regroup, R1, R2, q1t_tau = _factor_and_select(Wd, params_r, tol_qr, null_pivots, tau=tau)
     numrank_W = len(idx_base)
-    R1, R2, q1t_tau = _regroup(R, idx_base, idx_regroup, True)
     with single_threaded_blas():
         R1_inv = np.linalg.inv(R1)
         beta = np.around(np.dot(R1_inv, R2), 6)

@@ -1,0 +1,49 @@
+"""Which BASELINE configs certify the null-pivot rule (round 6)?  Prints the coefficient sums, the tightest margins and whether the
+pipeline fell back.  python tools/cert_report.py [cfg2 cfg3 ...]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from figaroh_plus_amd import _lib
+from figaroh_plus_amd._host import null_rule_certified
+from figaroh_plus_amd.pipeline import IdentificationPipeline
+from figaroh_plus_amd.tools.randomdata import sample_inputs
+from figaroh_plus_amd.tools.robot import Robot
+CFG = {"cfg1": ("cfg1_tx40", "tx40", 50000), "cfg2": ("cfg2_ur10", "ur10", 1_000_000), "cfg3": ("cfg3_tiago", "tiago", 1_000_000),
+       "cfg4": ("cfg4_talos", "talos", 1_000_000), "cfg5": ("cfg5_human", "human", 2_000_000)}
+for c in (sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]):
+    fixture, model, N = CFG[c]
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", fixture + ".json")))
+    robot = Robot.from_flat(model)
+    rng = np.random.default_rng(20250410 + int(c[3]))
+    if c == "cfg2":
+        q, v, a = (rng.uniform(-6, 6, (N, 6)) for _ in range(3))
+    elif c == "cfg1":
+        q, v, a = rng.uniform(-6, 6, (N, 6)), rng.uniform(-10, 10, (N, 6)), rng.uniform(-30, 30, (N, 6))
+    else:
+        q, v, a = sample_inputs(robot.model, N, rng, 1.5, 2, 5)
+    pipe = IdentificationPipeline(robot, meta["param"], params_std=dict(zip(meta["names_std"], meta["phi_ref_raw"])), coupling=meta["coupling"],
+                                  w_layout="block-compact" if c == "cfg3" else "dense")
+    pipe.set_samples(q, v, a)
+    pipe.set_tau_from_parameters(np.array([float(x) for x in meta["phi_ref_raw"]]), noise_std=0.05)
+    out = pipe.run(); out = pipe.run()
+    cache = pipe._cert_cache
+    d = out["absdiagR"]; b = np.asarray(out["idx_base"]); dep = np.setdiff1d(np.arange(len(d)), b)
+    line = "%s N %d: n_base %d, fallbacks %d, rule now %s" % (c, N, len(b), pipe.null_rule_fallbacks, pipe.null_pivots)
+    if cache is not None and cache[1] is not None:
+        Ab, Ad = cache[1]
+        mb = (d[b] - 1e-8) / ((1 + Ab) * 2e-8 / 64); md = (1e-8 - d[dep]) / ((1 + Ad) * 2e-8 / 64) if len(dep) else np.array([np.inf])
+        line += "; A_base max %.2f, A_dep max %.2f; tightest margin / bound: base %.2f (pivot %.4g, A %.2f), dependent %.2f" % (
+            Ab.max(), Ad.max() if len(Ad) else 0, mb.min(), d[b][mb.argmin()], Ab[mb.argmin()], md.min())
+    failed = getattr(pipe, "_cert_failed", None)
+    if failed is not None and failed[0] is not None and failed[0][1] is not None:
+        (Ab, Ad), d0, b0 = failed[0][1], failed[1], np.asarray(failed[2])
+        dep0 = np.setdiff1d(np.arange(len(d0)), b0)
+        mb = (d0[b0] - 1e-8) / ((1 + Ab) * 1e-8 / 64)
+        md = (1e-8 - d0[dep0]) / ((1 + Ad) * 1e-8 / 64)
+        k = np.argsort(mb)[:4]; j = np.argsort(md)[:3]
+        line += "; UNCERTIFIED pass: base (pivot, A, margin / bound at safety 1): %s; dependent: %s" % (
+            [(float("%.4g" % d0[b0][i]), float("%.2f" % Ab[i]), float("%.2f" % mb[i])) for i in k],
+            [(float("%.4g" % d0[dep0][i]), float("%.2f" % Ad[i]), float("%.2f" % md[i])) for i in j])
+    print(line, flush=True)
+    del pipe
