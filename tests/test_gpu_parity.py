@@ -3055,3 +3055,12 @@ def test_tree_walks_fuzz(lib, oracle_lib, seed):
     assert outs[0]["idx_e"] == outs[1]["idx_e"] and outs[0]["idx_base"] == outs[1]["idx_base"]
     assert abs(outs[0]["residual_norm"] - outs[1]["residual_norm"]) <= 1e-9 * max(1.0, outs[0]["residual_norm"]), (
         outs[0]["residual_norm"], outs[1]["residual_norm"], float(np.linalg.norm(tau)), parents)
+    # (round 6) ... and the classification is LAPACK's on the oracle's matrix, wherever LAPACK's own pivots keep clear of the
+    # tolerances (random inertias make ill-conditioned models: this is what found the spurious base parameters of the unguarded
+    # null-pivot rule, tools/fuzz_trees.py)
+    idx_e = [int(i) for i in range(W_ref.shape[1]) if ref_sq[i] < 1e-6]
+    kept = [i for i in range(W_ref.shape[1]) if not ref_sq[i] < 1e-6]
+    d_ref = np.abs(np.diag(np.linalg.qr(W_ref[:, kept], mode="r")))
+    if np.abs(d_ref - 1e-8).min() > 0.5e-8 and np.abs(ref_sq - 1e-6).min() > 0.5e-6:
+        assert outs[0]["idx_e"] == idx_e
+        assert outs[0]["idx_base"] == [i for i in range(len(kept)) if d_ref[i] > 1e-8], parents
