@@ -66,6 +66,78 @@ def check(robot, param, q, v, a, variants, seed, what):
     return clear, sum(fb for _, _, fb, _ in outs), max(fp for _, _, _, fp in outs)
 
 
+def check_extras(robot, param, q, v, a, seed, what, freeflyer):
+    """Second campaign: the streamed pass (chunk_samples) against the resident one, the weighted solve in every layout against the
+    script formula (examples/staubli_TX40/identification.py:305-346) evaluated with NumPy on the oracle's W, and -- fixed-base trees
+    -- active row blocks against the oracle's stacked blocks."""
+    m = robot.model
+    rng = np.random.default_rng(11 + seed)
+    mode, fl, ft = oracle_c.param_flags(param, False)
+    W_ref = oracle_c.OracleModel(m.to_flat()).build_regressor_basic(q, v, a, mode, fl, ft)
+    params_std = robot.get_standard_parameters(param)
+    tau = W_ref @ np.array(list(params_std.values()), dtype=float) + 1e-2 * rng.standard_normal(len(W_ref))
+    N = len(q)
+    nblocks = 6 if freeflyer else m.nv
+    base = IdentificationPipeline(robot, param, params_std=params_std, null_pivots=False)
+    base.set_samples(q, v, a, tau)
+    ref = base.run(wls=True)
+    kept = [i for i in range(W_ref.shape[1]) if i not in set(ref["idx_e"])]
+    d = ref["absdiagR"]
+    b = np.asarray(ref["idx_base"])
+    cond = d[b].max() / d[b].min()
+    if np.abs(d - TOL_QR).min() < 0.5 * TOL_QR or cond > 1e9:
+        return False  # (a decision of its own near the tolerance, or a base regressor too ill-conditioned to compare phi_wls)
+    # the script's weighted least squares on the host
+    Wb = W_ref[:, kept][:, ref["idx_base"]]
+    phi_b = np.round(np.linalg.lstsq(Wb, tau, rcond=None)[0], 6)
+    res = (tau - Wb @ phi_b).reshape(nblocks, N)
+    sig2 = (res * res).sum(axis=1) / N
+    wgt = np.repeat(1.0 / np.sqrt(sig2), N)
+    phi_w = np.linalg.lstsq(Wb * wgt[:, None], tau * wgt, rcond=None)[0]
+    tolw = max(2e-6, 1e4 * np.finfo(float).eps * cond) * max(1.0, np.abs(phi_w).max())
+    layouts = ["dense"] + ([] if freeflyer else ["block-compact"])
+    for layout in layouts:
+        for rule in (True, False):
+            pipe = IdentificationPipeline(robot, param, params_std=params_std, w_layout=layout, null_pivots=rule)
+            pipe.set_samples(q, v, a, tau)
+            pipe.run(wls=True)
+            o = pipe.run(wls=True)
+            assert o["idx_base"] == ref["idx_base"] and o["idx_e"] == ref["idx_e"], (what, seed, layout, rule)
+            # (phi_b is the OLS solution ROUNDED to 6 decimals, as in the script: a parameter of magnitude 2e5 on a base regressor of
+            # condition 1e5 is only determined to a few 1e-6, LAPACK's SVD solve and the Householder triangle then round differently
+            # and the variances move with it -- seed 103: 11 entries differ by up to 6e-6, sigma2 by 3.6e-5 relative)
+            flips = bool((o["phi_b"] != phi_b).any())
+            assert np.abs(o["phi_b"] - phi_b).max() <= max(2e-6, 1e-10 * np.abs(phi_b).max())
+            assert np.abs(o["sigma2_joint"] - sig2).max() <= (1e-3 if flips else 1e-6) * sig2.max(), (
+                what, seed, layout, rule, "sigma2", float(np.abs(o["sigma2_joint"] - sig2).max() / sig2.max()), cond,
+                float(np.abs(phi_b).max()), int((o["phi_b"] != phi_b).sum()), float(np.abs(o["phi_b"] - phi_b).max()))
+            assert np.abs(o["phi_wls"] - phi_w).max() <= tolw, (what, seed, layout, rule, "phi_wls", np.abs(o["phi_wls"] - phi_w).max(), cond)
+            del pipe
+    # streamed in chunks
+    chunk = 64 * int(rng.integers(1, max(2, N // 128)))
+    pipe = IdentificationPipeline(robot, param, params_std=params_std, chunk_samples=chunk)
+    pipe.set_samples(q, v, a, tau)
+    pipe.run()
+    o = pipe.run()
+    assert o["idx_base"] == ref["idx_base"] and o["idx_e"] == ref["idx_e"], (what, seed, "chunked", chunk)
+    assert np.abs(o["phi_ls"] - ref["phi_ls"]).max() <= max(1e-6, 1e3 * np.finfo(float).eps * cond) * max(1.0, np.abs(ref["phi_ls"]).max())
+    del pipe
+    if not freeflyer and m.nv >= 4:  # active row blocks: columns eliminated on ALL blocks, factored on the listed ones
+        act = sorted(int(x) for x in rng.choice(m.nv, size=max(2, m.nv // 2), replace=False))
+        tau_act = np.concatenate([tau[j * N:(j + 1) * N] for j in act])
+        pipe = IdentificationPipeline(robot, param, params_std=params_std, w_layout="block-compact", row_blocks=act)
+        pipe.set_samples(q, v, a, tau_act)
+        pipe.run()
+        o = pipe.run()
+        assert o["idx_e"] == ref["idx_e"], (what, seed, "active: idx_e")
+        Wa = np.vstack([W_ref[j * N:(j + 1) * N] for j in act])[:, kept]
+        da = np.abs(np.diag(np.linalg.qr(Wa, mode="r")))
+        if np.abs(da - TOL_QR).min() > 0.5 * TOL_QR:
+            assert o["idx_base"] == [i for i in range(len(kept)) if da[i] > TOL_QR], (what, seed, "active: idx_base", act)
+        del pipe
+    return True
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = nclear = nfall = nfused = 0
@@ -93,6 +165,22 @@ for seed in range(first, first + count):
             variants = [dict(w_layout="dense"), dict(w_layout="block-compact"), dict(w_layout="block-compact", null_pivots=False),
                         dict(w_layout="dense", null_pivots=False)]
             what = "tree%d" % n
+        if len(sys.argv) > 3 and sys.argv[3] == "extras":
+            if what.startswith("chain"):
+                continue
+            if seed % 2:  # every other tree gets a free-flyer root and the external-wrench regressor
+                robot = T._synthetic_tree([0] + [p + 1 for p in parents], seed=seed, massless=tuple(k + 1 for k in massless), freeflyer=True)
+                param = dict(param, is_joint_torques=False, is_external_wrench=True, has_friction=False, has_actuator_inertia=False,
+                             has_joint_offset=False, force_torque=["All"])
+                N = 64 * 90 + int(rng.integers(1, 64))
+                m2 = robot.model
+                q = np.zeros((N, m2.nq))
+                quat = rng.standard_normal((N, 4))
+                q[:, :3], q[:, 3:7] = rng.uniform(-1, 1, (N, 3)), quat / np.linalg.norm(quat, axis=1)[:, None]
+                q2, v, a = inputs(m2, N, rng)
+                q[:, 7:] = q2[:, 7:]
+            nclear += bool(check_extras(robot, param, q, v, a, seed, what, freeflyer=bool(seed % 2)))
+            continue
         clear, fb, fp = check(robot, param, q, v, a, variants, seed, what)
         nclear += clear
         nfall += fb
