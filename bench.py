@@ -668,9 +668,20 @@ def spawn_ranks(n):
     import socket
     import subprocess
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = None
+    for _ in range(50):  # (MASTER_PORT and MASTER_PORT + 101, where the socket control plane listens, both free)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            cand = s.getsockname()[1]
+        try:
+            with socket.socket() as s2:
+                s2.bind(("127.0.0.1", cand + 101))
+            port = cand
+            break
+        except (OSError, OverflowError):
+            continue
+    if port is None:
+        raise SystemExit("bench.py: no free port pair for the rank processes")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),

@@ -11,9 +11,21 @@ from conftest import GOLD, ROOT
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    """A port p with p + 101 free as well: MASTER_PORT belongs to the launcher's store, the socket control plane listens on
+    MASTER_PORT + 101 (dist.SocketGroup.PORT_OFFSET) -- checking only p left a rare collision on p + 101."""
+    for _ in range(50):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        if port + 101 > 65535:
+            continue
+        try:
+            with socket.socket() as s2:
+                s2.bind(("127.0.0.1", port + 101))
+            return port
+        except OSError:
+            continue
+    raise RuntimeError("no free port pair")
 
 
 def _worker(rank, world, port, out_dir):
