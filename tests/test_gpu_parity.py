@@ -25,6 +25,22 @@ def lib():
     return _lib
 
 
+def _free_port_pair():
+    """A port p with p + 101 free as well (the socket control plane of dist.SocketGroup listens on MASTER_PORT + 101)."""
+    import socket
+    for _ in range(50):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        try:
+            with socket.socket() as s2:
+                s2.bind(("127.0.0.1", port + 101))
+            return port
+        except (OSError, OverflowError):
+            continue
+    raise RuntimeError("no free port pair")
+
+
 def _oracle_W(g, oracle_lib, q, v, a, param=None, coupling=None):
     om = oracle_lib.OracleModel(g.flat())
     mode, flags, ft = oracle_lib.param_flags(param or g.param, g.coupling if coupling is None else coupling)
@@ -1556,9 +1572,7 @@ def test_two_process_pipeline_on_one_device(lib, golden_ur10, tmp_path):
     import sys
     from conftest import ROOT
     g = golden_ur10
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_port_pair()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
@@ -1586,9 +1600,7 @@ def _two_device_ranks(tmp_path, models, same_device=False):
     import subprocess
     import sys
     from conftest import ROOT
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_port_pair()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0" if same_device else str(rank),
@@ -1666,9 +1678,7 @@ def test_bench_two_ranks_share_the_device(lib):
     from conftest import ROOT
 
     def run(extra):
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
+        port = _free_port_pair()
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         for k in [k for k in env if k.startswith("FIGH_")]:
             del env[k]
@@ -1729,9 +1739,7 @@ def test_bench_two_ranks_socket_rendezvous(lib):
     import subprocess
     import sys
     from conftest import ROOT
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_port_pair()
     procs = []
     for rank in range(2):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
