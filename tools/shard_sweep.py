@@ -24,7 +24,7 @@ RCCL_CALL_US = 30.0
 
 def step_ms(cfg, samples, steps):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--samples", str(samples), "--steps", str(steps),
-           "--warmup", "2", "--no-cpu-baseline", "--scaling", "strong"]
+           "--warmup", "2", "--no-cpu-baseline", "--scaling", "strong", "--strong-config="]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     return line["ms_per_step_median"], {k: v.get("avg_ms") for k, v in line["kernels"].items()}, line["config"]["kept_columns"]
