@@ -411,7 +411,13 @@ hipError_t bulk_copy(char *h, char *d, const size_t bytes, const bool to_host) {
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 0; t < nt; ++t) pool.emplace_back(worker, t);
+    try {
+        for (int t = 0; t < nt; ++t) pool.emplace_back(worker, t);
+    } catch (...) {  // (thread limit of the container: the caller takes the one-piece copy instead)
+        abort.store(true);
+        for (auto &t : pool) t.join();
+        return hipErrorNotReady;
+    }
     // (per CHUNK: a global count of thread-chunks would let a fast thread's next chunk stand in for a slow thread's current one)
     auto wait_chunk = [&](long k) { while (done[k].load(std::memory_order_acquire) < nt) std::this_thread::yield(); };
     hipError_t err = hipSuccess;
@@ -453,8 +459,11 @@ int figh_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes) {
     if (int rc = ensure_device()) return rc;
     if (bytes >= kBulkMin && !is_pinned(h_src, bytes) && bulk_ready()) {
         FIGH_HIP(hipStreamSynchronize(g_stream));  // (the staging buffers may still feed an earlier copy)
-        FIGH_HIP(bulk_copy(const_cast<char *>(static_cast<const char *>(h_src)), static_cast<char *>(d_dst), bytes, false));
-        return FIGH_OK;
+        const hipError_t e = bulk_copy(const_cast<char *>(static_cast<const char *>(h_src)), static_cast<char *>(d_dst), bytes, false);
+        if (e != hipErrorNotReady) {  // (hipErrorNotReady: the copy threads could not be started -- nothing was copied)
+            FIGH_HIP(e);
+            return FIGH_OK;
+        }
     }
     void *stage = bytes <= kPinnedBytes ? pinned_staging() : nullptr;
     if (stage) {
@@ -513,8 +522,11 @@ int figh_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes) {
         return FIGH_OK;
     }
     if (bytes >= kBulkMin && !is_pinned(h_dst, bytes) && bulk_ready()) {
-        FIGH_HIP(bulk_copy(static_cast<char *>(h_dst), const_cast<char *>(static_cast<const char *>(d_src)), bytes, true));
-        return FIGH_OK;
+        const hipError_t e = bulk_copy(static_cast<char *>(h_dst), const_cast<char *>(static_cast<const char *>(d_src)), bytes, true);
+        if (e != hipErrorNotReady) {
+            FIGH_HIP(e);
+            return FIGH_OK;
+        }
     }
     FIGH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_stream));
     FIGH_HIP(hipStreamSynchronize(g_stream));
