@@ -1665,6 +1665,20 @@ def test_rccl_two_devices_primitives_and_pipeline(lib, tmp_path):
     _check_two_rank_results(_two_device_ranks(tmp_path, ["cfg2_ur10", "cfg4_talos"]), want_rccl=True)
 
 
+def test_sharded_pass_on_random_models_with_a_replay_exchange(lib):
+    """The collective code paths of the pipeline (all-reduced norms, non-local rank decision, stacked triangles through
+    figh_tsqr_merge_base) on random models in ONE process: tools/fuzz_sharded.py splits the samples into two or three unequal
+    shards, runs one pipeline per shard under an exchange of world size > 1 that replays the other shards' contributions, and
+    compares with the single-rank pass on all samples -- serial chains (fused launch), fixed-base trees (per-row-block TSQR,
+    both layouts), floating-base trees (force / torque split).  900 seeds in round 6; twelve here."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sharded.py"), "0", "12"], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=600).stdout.decode()
+    assert "12 sharded random models (seeds 0 .. 11), 0 failures" in out, out[-3000:]
+
+
 def test_bench_two_ranks_share_the_device(lib):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU a test
     box has: both ranks drive device 0, so the exchange must be negotiated down to the host-staged one on every rank
