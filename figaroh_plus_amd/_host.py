@@ -113,7 +113,7 @@ def null_rule_bounds(R1, R2):
     from scipy.linalg.lapack import dtrtri
     r = R1.shape[0]
     if r == 0:
-        return np.zeros(0), np.zeros(R2.shape[1] if R2.ndim == 2 else 0)
+        return np.zeros(0), np.zeros(R2.shape[1] if R2.ndim == 2 else 0), 0.0
     if not np.diag(R1).all():
         return None
     X, info = dtrtri(np.ascontiguousarray(R1), lower=0)
@@ -122,10 +122,10 @@ def null_rule_bounds(R1, R2):
     X = np.triu(X)
     A_base = np.abs(np.diag(R1)) * (np.abs(X).sum(axis=0) - np.abs(np.diag(X)))
     A_dep = np.abs(X @ R2).sum(axis=0) if R2.size else np.zeros(0)
-    return A_base, A_dep
+    return A_base, A_dep, float(np.abs(X).sum(axis=1).max())  # (the last: the infinity norm of R1^-1, for the bound on phi)
 
 
-def null_rule_certified(absdiag, idx_base, idx_regroup, bounds, tol_qr, safety=2.0):
+def null_rule_certified(absdiag, idx_base, idx_regroup, bounds, tol_qr, safety=2.0, phi=None):
     """A-posteriori GUARD for a factorisation that ran WITH the null-pivot rule (``figh_tsqr_null_pivot_tol``): True when the
     classification ``|R_kk| > tol_qr`` can be trusted to be the one plain Householder -- the reference's ``np.linalg.qr``,
     qrdecomposition.py:205-221 -- gives on the same matrix; not certified = the caller repeats the factorisation WITHOUT the
@@ -145,6 +145,12 @@ def null_rule_certified(absdiag, idx_base, idx_regroup, bounds, tol_qr, safety=2
       its own (TIAGo at 4e5 samples: 6.7e-9) may have had ALL of it folded -- over T level-0 triangles the folded parts add up
       to ``sqrt(T) tol_qr / 64`` in the worst case, include/figh.h -- and its direction then leaks into the columns behind it;
       the rounding residue of an exactly dependent column stays far below (1e-12 .. 1.5e-10 at 1e7 samples);
+    * with ``phi`` (the least-squares solution of the pass): the solution itself is within reach of the perturbation when
+      ``|R1^-1|_inf (tol_qr / 64) |phi|_1 > 1e-7 max(1, |phi|_inf)`` -- phi solves the problem of ``W_b + E_b`` instead of ``W_b``,
+      ``|d phi|_inf <= |R1^-1|_inf |E_b phi|`` -- a tenth of north_star's 1e-6 on the estimates.  Plain Householder's own
+      error is ``cond eps``; the rule's is ``cond tol_qr / (64 |W_b|)``, some 1e4 times that, harmless for the BASELINE robots
+      (cond(W_b) 1e2 .. 1e4) and not for an ill-conditioned base regressor (found by tools/fuzz_trees.py: two layouts of one
+      random model, one under the rule and one not, residuals 1e-5 apart);
     * finite numbers throughout.
 
     For the five BASELINE robots A <= 9 and UR10, TALOS and the human model are certified at their full sizes; TIAGo, whose
@@ -154,8 +160,12 @@ def null_rule_certified(absdiag, idx_base, idx_regroup, bounds, tol_qr, safety=2
     import numpy as np
     if bounds is None:
         return False
-    A_base, A_dep = bounds
+    A_base, A_dep, xnorm = bounds
     fold = safety * tol_qr / NULL_RULE_FOLD
+    if phi is not None:
+        phi = np.abs(np.asarray(phi, dtype=np.float64))
+        if not np.isfinite(phi).all() or xnorm * (tol_qr / NULL_RULE_FOLD) * phi.sum() > 1e-7 * max(1.0, phi.max(initial=0.0)):
+            return False
     d = np.abs(np.asarray(absdiag, dtype=np.float64))
     db, dd = d[np.asarray(idx_base, dtype=np.int64)], d[np.asarray(idx_regroup, dtype=np.int64)]
     if not (np.isfinite(db).all() and np.isfinite(dd).all()):

@@ -922,18 +922,17 @@ class IdentificationPipeline:
         assert len(params_r) == n, "params_r does not have same length with R"
         Rb = rows_k[base]
         R1, R2, z = Rb[:, base], Rb[:, rest], (Rb[:, n] if with_tau else None)
-        certified = True
         if self.null_pivots:
             # the certificate of the null-pivot rule (_host.null_rule_certified): the coefficient sums come from the regrouped
             # triangle and are kept while the two index sets stay the same (they are properties of the model's geometry far more
             # than of the samples); the margins are this pass's own pivots
-            from ._host import null_rule_bounds, null_rule_certified
+            from ._host import null_rule_bounds
             key = (n, base.tobytes())
             cache = getattr(self, "_cert_cache", None)
             if cache is None or cache[0] != key:
                 with _single_threaded_blas(n):
                     cache = self._cert_cache = (key, null_rule_bounds(np.triu(R1), R2))
-            certified = null_rule_certified(diag[:n], idx_base, idx_regroup, cache[1], self.tol_qr)
+            self._cert_args = (diag[:n].copy(), idx_base, idx_regroup, cache[1])  # (phi joins below, once it is solved)
         # inv(R1) of qrdecomposition.py:244 by LAPACK's triangular inverse (dtrtri): R1 is upper triangular (the routine
         # reads the upper triangle only; below it the device leaves rounding residues), and np.linalg.inv's general LU
         # path pays ~30 us of BLAS thread start-up per call on a many-core host
@@ -962,7 +961,9 @@ class IdentificationPipeline:
             "col_norm": col_norm, "absdiagR": diag[:n].copy(), "rows": total_rows,
         }
         if self.null_pivots:
-            out["null_rule_certified"] = certified
+            from ._host import null_rule_certified
+            d_, ib_, ir_, bounds_ = self._cert_args
+            out["null_rule_certified"] = null_rule_certified(d_, ib_, ir_, bounds_, self.tol_qr, phi=phi_ls if with_tau else None)
         if strings and beta is not None:
             out["params_base"] = qrd._expressions([params_r[i] for i in idx_base],
                                                   [params_r[i] for i in idx_regroup], beta)

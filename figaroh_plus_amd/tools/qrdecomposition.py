@@ -105,7 +105,11 @@ def _factor_and_select(Wd, params_r, tol_qr, null_pivots, tau=None):
             break
         with single_threaded_blas():
             bounds = null_rule_bounds(R1, R2)
-        if null_rule_certified(np.diag(R)[:n], idx_base, idx_regroup, bounds, tol_qr):
+        phi = None
+        if q1t_tau is not None and bounds is not None and len(idx_base):
+            with single_threaded_blas():
+                phi = np.linalg.solve(np.triu(R1), q1t_tau)  # (np.linalg.inv(R1) @ q1t_tau of the callers, for the bound on phi)
+        if null_rule_certified(np.diag(R)[:n], idx_base, idx_regroup, bounds, tol_qr, phi=phi):
             break
     return R, idx_base, idx_regroup, R1, R2, q1t_tau
 

@@ -340,27 +340,31 @@ def test_null_rule_certificate():
     tol = 1e-8
     R1 = np.array([[1.0, 2.0, -3.0], [0.0, 1e-3, 4e-3], [0.0, 0.0, 5.0]])
     R2 = np.c_[R1 @ np.ones(3), np.zeros(3)]  # first dependent column = 1 b0 + 1 b1 + 1 b2, second = 0
-    A_base, A_dep = null_rule_bounds(R1, R2)
+    A_base, A_dep, xnorm = null_rule_bounds(R1, R2)
+    assert xnorm == pytest.approx(np.abs(np.linalg.inv(R1)).sum(axis=1).max())
     # A_base[k] = sum |R1[:k,:k]^-1 R1[:k,k]|
     want = [0.0, 2.0, np.abs(np.linalg.solve(R1[:2, :2], R1[:2, 2])).sum()]
     assert np.allclose(A_base, want, rtol=1e-12)
     assert np.allclose(A_dep, [3.0, 0.0], rtol=1e-12)
     diag = np.array([1.0, 1e-3, 5.0, 1e-12, 0.0])
-    assert null_rule_certified(diag, [0, 1, 2], [3, 4], (A_base, A_dep), tol)
+    assert null_rule_certified(diag, [0, 1, 2], [3, 4], (A_base, A_dep, xnorm), tol)
     # a base pivot 2 % above the tolerance with A = 2: margin 2e-10 < 2 (1 + 2) 1.5625e-10 -> not certified
-    assert not null_rule_certified(np.array([1.0, 1.02e-8, 5.0, 1e-12, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep), tol)
+    assert not null_rule_certified(np.array([1.0, 1.02e-8, 5.0, 1e-12, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep, xnorm), tol)
     # ... 20 % above it is
-    assert null_rule_certified(np.array([1.0, 1.2e-8, 5.0, 1e-12, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep), tol)
+    assert null_rule_certified(np.array([1.0, 1.2e-8, 5.0, 1e-12, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep, xnorm), tol)
     # a dependent pivot just below the tolerance is not
-    assert not null_rule_certified(np.array([1.0, 1e-3, 5.0, 0.95e-8, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep), tol)
+    assert not null_rule_certified(np.array([1.0, 1e-3, 5.0, 0.95e-8, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep, xnorm), tol)
     # a dependent column with genuine content of its own (above tol / 8) may have been folded entirely: not certified
-    assert not null_rule_certified(np.array([1.0, 1e-3, 5.0, 2e-9, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep), tol)
-    assert null_rule_certified(np.array([1.0, 1e-3, 5.0, 1.5e-10, 1e-13]), [0, 1, 2], [3, 4], (A_base, A_dep), tol)
+    assert not null_rule_certified(np.array([1.0, 1e-3, 5.0, 2e-9, 0.0]), [0, 1, 2], [3, 4], (A_base, A_dep, xnorm), tol)
+    assert null_rule_certified(np.array([1.0, 1e-3, 5.0, 1.5e-10, 1e-13]), [0, 1, 2], [3, 4], (A_base, A_dep, xnorm), tol)
     # large regrouping coefficients: the folded 1.6e-10 could surface as a pivot above the tolerance
-    assert not null_rule_certified(diag, [0, 1, 2], [3, 4], (A_base, np.array([700.0, 0.0])), tol)
+    assert not null_rule_certified(diag, [0, 1, 2], [3, 4], (A_base, np.array([700.0, 0.0]), xnorm), tol)
     # a spurious base column shows as a tiny R1_kk with huge projection coefficients
     R1s = np.array([[1.0, 500.0], [0.0, 1.1e-7]])
-    Ab, Ad = null_rule_bounds(R1s, np.zeros((2, 0)))
-    assert Ab[1] == pytest.approx(500.0) and not null_rule_certified(np.array([1.0, 1.1e-7]), [0, 1], [], (Ab, Ad), tol)
+    Ab, Ad, xn = null_rule_bounds(R1s, np.zeros((2, 0)))
+    assert Ab[1] == pytest.approx(500.0) and not null_rule_certified(np.array([1.0, 1.1e-7]), [0, 1], [], (Ab, Ad, xn), tol)
+    # the estimates themselves: |R1^-1|_inf (tol / 64) |phi|_1 against 1e-7 |phi|_inf
+    assert null_rule_certified(diag, [0, 1, 2], [3, 4], (A_base, A_dep, 1.0), tol, phi=np.array([3.0, -2.0, 1.0]))
+    assert not null_rule_certified(diag, [0, 1, 2], [3, 4], (A_base, A_dep, 1e4), tol, phi=np.array([3.0, -2.0, 1.0]))
     assert null_rule_bounds(np.array([[1.0, 1.0], [0.0, 0.0]]), np.zeros((2, 0))) is None  # singular: never certified
     assert not null_rule_certified(diag, [0, 1, 2], [3, 4], None, tol)

@@ -31,13 +31,14 @@ for c in (sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]):
     d = out["absdiagR"]; b = np.asarray(out["idx_base"]); dep = np.setdiff1d(np.arange(len(d)), b)
     line = "%s N %d: n_base %d, fallbacks %d, rule now %s" % (c, N, len(b), pipe.null_rule_fallbacks, pipe.null_pivots)
     if cache is not None and cache[1] is not None:
-        Ab, Ad = cache[1]
+        Ab, Ad, xn = cache[1]
         mb = (d[b] - 1e-8) / ((1 + Ab) * 2e-8 / 64); md = (1e-8 - d[dep]) / ((1 + Ad) * 2e-8 / 64) if len(dep) else np.array([np.inf])
-        line += "; A_base max %.2f, A_dep max %.2f; tightest margin / bound: base %.2f (pivot %.4g, A %.2f), dependent %.2f" % (
-            Ab.max(), Ad.max() if len(Ad) else 0, mb.min(), d[b][mb.argmin()], Ab[mb.argmin()], md.min())
+        phi = np.abs(out["phi_ls"])
+        line += "; A_base max %.2f, A_dep max %.2f; tightest margin / bound: base %.2f (pivot %.4g, A %.2f), dependent %.2f; phi bound |R1^-1|_inf tol/64 |phi|_1 = %.2e against 1e-7 |phi|_inf = %.2e" % (
+            Ab.max(), Ad.max() if len(Ad) else 0, mb.min(), d[b][mb.argmin()], Ab[mb.argmin()], md.min(), xn * 1e-8 / 64 * phi.sum(), 1e-7 * max(1.0, phi.max()))
     failed = getattr(pipe, "_cert_failed", None)
     if failed is not None and failed[0] is not None and failed[0][1] is not None:
-        (Ab, Ad), d0, b0 = failed[0][1], failed[1], np.asarray(failed[2])
+        (Ab, Ad, xn), d0, b0 = failed[0][1], failed[1], np.asarray(failed[2])
         dep0 = np.setdiff1d(np.arange(len(d0)), b0)
         mb = (d0[b0] - 1e-8) / ((1 + Ab) * 1e-8 / 64)
         md = (1e-8 - d0[dep0]) / ((1 + Ad) * 1e-8 / 64)
