@@ -350,10 +350,12 @@ class IdentificationPipeline:
         # provably plain Householder's -- a pivot close to tol_qr, or regrouping coefficients large enough for the folded
         # tol_qr / 64 to matter -- the pass is repeated without the rule and the rule stays off for this pipeline.)
         for _ in range(2):
+            fused_before = self.fused_passes
             with _lib.null_pivots(self.tol_qr if self.null_pivots else None):
                 out = self._run_once(strings, wls)
             if self.null_pivots and not out.get("null_rule_certified", True):
                 self.null_pivots = False
+                self.fused_passes = fused_before  # (counts the passes whose results were returned, not the discarded attempt)
                 self.null_rule_fallbacks = getattr(self, "null_rule_fallbacks", 0) + 1
                 # (kept for diagnostics, tools/cert_report.py: the bounds and the pivots of the pass that was not certified)
                 self._cert_failed = (self._cert_cache, out["absdiagR"].copy(), list(out["idx_base"]))
