@@ -368,3 +368,21 @@ def test_null_rule_certificate():
     assert not null_rule_certified(diag, [0, 1, 2], [3, 4], (A_base, A_dep, 1e4), tol, phi=np.array([3.0, -2.0, 1.0]))
     assert null_rule_bounds(np.array([[1.0, 1.0], [0.0, 0.0]]), np.zeros((2, 0))) is None  # singular: never certified
     assert not null_rule_certified(diag, [0, 1, 2], [3, 4], None, tol)
+
+
+def test_bench_spawns_rank_processes_and_relays_their_failure():
+    """`python bench.py --gpus 2` with no launcher (WORLD_SIZE unset) starts two rank processes itself (bench.spawn_ranks) and exits
+    with a child's non-zero code when they fail -- here because this container has no HIP device and the product has no CPU path
+    (the GPU box runs the same command to completion: test_bench_spawns_its_own_ranks)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("FIGH_")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode()
+    if "needs a HIP device" in out:  # (the CPU container; on a GPU box the ranks run, which the GPU suite checks)
+        assert p.returncode != 0 and out.count("needs a HIP device") == 2, out[-2000:]
+    else:
+        assert p.returncode == 0 and out.count('"n_gpus": 2') == 1, out[-2000:]
