@@ -95,7 +95,9 @@ class GpuMatrix:
         full = host_empty((self.rows, self.ld))
         if full.size:
             _lib.check(_lib.load().figh_memcpy_d2h(full.ctypes.data, self.buf.ptr, full.nbytes))
-        return np.ascontiguousarray(full[:, :self.cols])
+        out = host_empty((self.rows, self.cols))
+        out[...] = full[:, :self.cols]
+        return out
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
